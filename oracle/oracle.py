@@ -1,0 +1,527 @@
+"""CPU oracle for the DiffAlign denoiser + reverse-diffusion hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``diffalign_amd/`` imports this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.
+
+It is a from-scratch plain-PyTorch (CPU, fp32) restatement of the reference algorithm.
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  Parity is PINNED: ``tests/golden/make_golden.py`` imports the
+reference in the build container, runs it on seeded synthetic inputs and commits the
+inputs/outputs as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this
+file against every one of those vectors.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# a1  container semantics: PlaceHolder.mask / encode_no_element
+# --------------------------------------------------------------------------------------
+def encode_no_element(A: Tensor) -> Tensor:
+    """utils/placeholder.py:9-18 -- any all-zero (sum == 0) feature vector gets channel 0 := 1."""
+    if A.shape[-1] == 0:
+        return A
+    A = A.clone()
+    empty = A.sum(dim=-1) == 0
+    first = A[..., 0]
+    first[empty] = 1
+    A[..., 0] = first
+    return A
+
+
+def mask_dense(X: Tensor, E: Tensor, node_mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """utils/placeholder.py:81-102 (collapse=False)."""
+    m = node_mask.to(X.dtype)
+    X = X * m[:, :, None]
+    E = E * m[:, :, None, None] * m[:, None, :, None]
+    n = E.shape[1]
+    eye = torch.eye(n, dtype=torch.bool)
+    E = E.clone()
+    E[:, eye] = 0
+    return encode_no_element(X), encode_no_element(E)
+
+
+def collapse_dense(X: Tensor, E: Tensor, node_mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """utils/placeholder.py:90-94 (collapse=True): argmax then zero masked."""
+    Xi = X.argmax(-1)
+    Ei = E.argmax(-1)
+    Xi = Xi * node_mask.long()
+    pair = node_mask[:, :, None] & node_mask[:, None, :]
+    Ei = Ei * pair.long()
+    return Xi, Ei
+
+
+# --------------------------------------------------------------------------------------
+# a2  free-to-diffuse masks (closed form of utils/graph.py:462-619)
+# --------------------------------------------------------------------------------------
+def free_masks(orig_X: Tensor, node_mask: Tensor, atom_map_numbers: Optional[Tensor], mode: Optional[str],
+               suno_idx: int, state_idx_to_mask: Sequence[int] = (0,), include_supernode: bool = True
+               ) -> Tuple[Tensor, Tensor]:
+    """Per-node masks (mask_x, mask_e), True = free to diffuse.
+
+    utils/graph.py:565-594 get_mask_product: mask[b,i] = (i <= lastSuNo[b]) and (i != n-1)
+    utils/graph.py:536-563 get_mask_sn (one SuNo per graph): mask[b,i] = (i != SuNo position)
+    utils/graph.py:488-493 'product_and_sn' = product * sn; :500-508 'atom_mapping'
+    utils/graph.py:524-529 state mask: argmax(orig.X) not in node_idx_to_mask (always holds
+    'none'=0 because get_index_from_states appends it, :679-680)
+    """
+    B, n, _ = orig_X.shape
+    cls = orig_X.argmax(-1)
+    ar = torch.arange(n)[None, :].expand(B, n)
+    is_suno = cls == suno_idx
+    last_suno = torch.where(is_suno, ar, torch.full_like(ar, -1)).max(-1).values  # (B,)
+    m_prod = (ar <= last_suno[:, None]) & (ar != n - 1)
+    if include_supernode:
+        # single SuNo per graph on this path: the (last) SuNo position is excluded
+        m_sn = ar != last_suno[:, None]
+    else:
+        m_sn = node_mask.clone()
+    if mode == 'product':
+        mx = me = m_prod
+    elif mode == 'sn':
+        mx = me = m_sn
+    elif mode == 'product_and_sn':
+        mx = me = m_prod & m_sn
+    elif mode == 'reactant':
+        mx = me = ~(m_prod & m_sn)
+    elif mode == 'reactant_and_sn':
+        mx = me = (~(m_prod & m_sn)) & m_sn
+    elif mode == 'atom_mapping':
+        me = m_prod & m_sn
+        mx = (atom_map_numbers == 0) & me
+    else:
+        mx = me = node_mask.clone()
+    st = torch.ones_like(mx)
+    for s in state_idx_to_mask:
+        st &= cls != s
+    return mx & st, me & st
+
+
+def expand_masks(mask_x: Tensor, mask_e: Tensor, Kx: int, Ke: int) -> Tuple[Tensor, Tensor]:
+    """utils/graph.py:607-619: mask_X[b,i,:]=mask_x[b,i]; mask_E[b,i,j,:]=mask_e[b,i]&mask_e[b,j]."""
+    mX = mask_x[:, :, None].expand(-1, -1, Kx)
+    mE = (mask_e[:, :, None] & mask_e[:, None, :])[..., None].expand(-1, -1, -1, Ke)
+    return mX, mE
+
+
+def apply_mask(orig_X: Tensor, orig_E: Tensor, z_X: Tensor, z_E: Tensor, mask_x: Tensor, mask_e: Tensor,
+               as_logits: bool = False) -> Tuple[Tensor, Tensor]:
+    """utils/graph.py:440-455: where not free take orig (x100 if as_logits) else z."""
+    scale = 100.0 if as_logits else 1.0
+    mX = mask_x[:, :, None]
+    mE = (mask_e[:, :, None] & mask_e[:, None, :])[..., None]
+    return torch.where(mX, z_X, orig_X * scale), torch.where(mE, z_E, orig_E * scale)
+
+
+# --------------------------------------------------------------------------------------
+# a5  transition tables
+# --------------------------------------------------------------------------------------
+def cosine_betas_discrete(timesteps: int, s: float = 0.0) -> np.ndarray:
+    """utils/diffusion/helpers.py:634-643 (called with s=0, noise_schedule.py:53)."""
+    steps = timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(0.5 * np.pi * ((x / steps) + s) / (1 + s)) ** 2
+    ac = ac / ac[0]
+    return (1 - ac[1:] / ac[:-1]).squeeze()
+
+
+def _fix_masked_states(Q: Tensor, idx: Optional[Sequence[int]]) -> Tensor:
+    """noise_schedule.py:98-121: zero rows/cols of masked states, diagonal 1, renormalise rows."""
+    Q = Q.clone()
+    if idx is not None:
+        idx = list(idx)
+        Q[..., :, idx] = 0.
+        Q[..., idx, :] = 0.
+        Q[..., idx, idx] = 1.
+    return Q / Q.sum(-1, keepdim=True)
+
+
+def _finish(tables: Dict[str, Tensor], x_limit: Tensor, e_limit: Tensor, y_limit: Tensor,
+            node_idx_to_mask, edge_idx_to_mask) -> Dict[str, Tensor]:
+    out = dict(
+        Qt_x=_fix_masked_states(tables['Qt_x'], node_idx_to_mask),
+        Qt_e=_fix_masked_states(tables['Qt_e'], edge_idx_to_mask),
+        Qtb_x=_fix_masked_states(tables['Qtb_x'], node_idx_to_mask),
+        Qtb_e=_fix_masked_states(tables['Qtb_e'], edge_idx_to_mask),
+        Qt_y=tables['Qt_y'], Qtb_y=tables['Qtb_y'],
+    )
+    x_limit = x_limit.clone(); e_limit = e_limit.clone()
+    if node_idx_to_mask is not None:
+        x_limit[list(node_idx_to_mask)] = 0.
+    if edge_idx_to_mask is not None:
+        e_limit[list(edge_idx_to_mask)] = 0.
+    out['x_limit'] = x_limit / x_limit.sum()
+    out['e_limit'] = e_limit / e_limit.sum()
+    out['y_limit'] = y_limit
+    return out
+
+
+def absorbing_tables(T: int, Kx: int, Ke: int, Ky: int, abs_x: int, abs_e: int = 0,
+                     node_idx_to_mask=None, edge_idx_to_mask=None) -> Dict[str, Tensor]:
+    """noise_schedule.py:294-326: Q_t=(1-b)I+b*1 e_abs^T, b=1/(T-t+1); Qbar_t=(1-t/T)I+(t/T)*1 e_abs^T."""
+    def fam(K, a):
+        eye = torch.eye(K)
+        absorb = torch.zeros(K, K); absorb[:, a] = 1.
+        Qt = [eye] + [1 / (T - t + 1) * absorb + (1 - 1 / (T - t + 1)) * eye for t in range(1, T + 1)]
+        Qb = [eye] + [t / T * absorb + (1 - t / T) * eye for t in range(1, T + 1)]
+        return torch.stack(Qt), torch.stack(Qb)
+    Qt_x, Qtb_x = fam(Kx, abs_x % Kx)
+    Qt_e, Qtb_e = fam(Ke, abs_e % Ke)
+    Qt_y, Qtb_y = fam(Ky + 1, Ky)
+    xl = torch.zeros(Kx); xl[abs_x % Kx] = 1.
+    el = torch.zeros(Ke); el[abs_e % Ke] = 1.
+    yl = torch.zeros(Ky + 1); yl[Ky] = 1.
+    return _finish(dict(Qt_x=Qt_x, Qtb_x=Qtb_x, Qt_e=Qt_e, Qtb_e=Qtb_e, Qt_y=Qt_y, Qtb_y=Qtb_y),
+                   xl, el, yl, node_idx_to_mask, edge_idx_to_mask)
+
+
+def _beta_alpha_bar(T: int) -> Tuple[Tensor, Tensor]:
+    """noise_schedule.py:63-70."""
+    betas = torch.from_numpy(cosine_betas_discrete(T, s=0)).float()
+    alphas = 1 - torch.clamp(betas, min=0, max=0.9999)
+    alphas_bar = torch.exp(torch.cumsum(torch.log(alphas), dim=0))
+    return betas, alphas_bar
+
+
+def marginal_tables(T: int, x_marginals: Tensor, e_marginals: Tensor, Ky: int,
+                    node_idx_to_mask=None, edge_idx_to_mask=None) -> Dict[str, Tensor]:
+    """noise_schedule.py:234-292: Q_t=(1-b_t)I+b_t 1 m^T; Qbar_t=abar_t I+(1-abar_t) 1 m^T."""
+    betas, abar = _beta_alpha_bar(T)
+    def fam(u):
+        K = u.shape[-1]
+        eye = torch.eye(K)
+        Qt = torch.stack([betas[t] * u + (1 - betas[t]) * eye for t in range(T + 1)])
+        Qb = torch.stack([abar[t] * eye + (1 - abar[t]) * u for t in range(T + 1)])
+        return Qt, Qb
+    ux = x_marginals.float()[None, :].expand(len(x_marginals), -1)
+    ue = e_marginals.float()[None, :].expand(len(e_marginals), -1)
+    uy = torch.ones(Ky, Ky) / max(Ky, 1)
+    Qt_x, Qtb_x = fam(ux); Qt_e, Qtb_e = fam(ue); Qt_y, Qtb_y = fam(uy)
+    return _finish(dict(Qt_x=Qt_x, Qtb_x=Qtb_x, Qt_e=Qt_e, Qtb_e=Qtb_e, Qt_y=Qt_y, Qtb_y=Qtb_y),
+                   x_marginals.float().clone(), e_marginals.float().clone(), torch.ones(Ky) / max(Ky, 1),
+                   node_idx_to_mask, edge_idx_to_mask)
+
+
+def uniform_tables(T: int, Kx: int, Ke: int, Ky: int, node_idx_to_mask=None, edge_idx_to_mask=None):
+    """noise_schedule.py:171-232."""
+    return marginal_tables(T, torch.ones(Kx) / Kx, torch.ones(Ke) / Ke, Ky, node_idx_to_mask, edge_idx_to_mask)
+
+
+# --------------------------------------------------------------------------------------
+# a14 posterior p(z_s | z_t) ; a15 sampling ; a6 initial noise ; a17 forward noising
+# --------------------------------------------------------------------------------------
+def _over0_posterior(z_t: Tensor, Qt: Tensor, Qsb: Tensor, Qtb: Tensor) -> Tensor:
+    """utils/diffusion/helpers.py:785-807.  z_t (B,N,K) one-hot; returns (B,N,K0,Ks)."""
+    a = z_t @ Qt.transpose(-1, -2)                         # (B,N,Ks): (x_t Q_t^T)[k]
+    num = a.unsqueeze(2) * Qsb.unsqueeze(1)                 # (B,N,K0,Ks)
+    den = (Qtb @ z_t.transpose(-1, -2)).transpose(-1, -2)   # (B,N,K0)
+    den = den.clone()
+    den[den == 0] = 1e-6
+    return num / den.unsqueeze(-1)
+
+
+def posterior_probs(logits_X: Tensor, logits_E: Tensor, zt_X: Tensor, zt_E: Tensor, node_mask: Tensor,
+                    Qt_x, Qsb_x, Qtb_x, Qt_e, Qsb_e, Qtb_e) -> Tuple[Tensor, Tensor]:
+    """helpers.py:193-229 get_p_zs_given_zt(return_prob=True).  Q* are per-graph (B,K,K)."""
+    B, n, Kx = zt_X.shape
+    Ke = zt_E.shape[-1]
+    pX = F.softmax(logits_X, -1)
+    pE = F.softmax(logits_E, -1).reshape(B, n * n, Ke)
+    wX = _over0_posterior(zt_X.float(), Qt_x, Qsb_x, Qtb_x)
+    wE = _over0_posterior(zt_E.reshape(B, n * n, Ke).float(), Qt_e, Qsb_e, Qtb_e)
+    uX = (pX.unsqueeze(-1) * wX).sum(2)
+    uX[uX.sum(-1) == 0] = 1e-5
+    uX = uX / uX.sum(-1, keepdim=True)
+    uE = (pE.unsqueeze(-1) * wE).sum(2)
+    uE[uE.sum(-1) == 0] = 1e-5
+    uE = (uE / uE.sum(-1, keepdim=True)).reshape(B, n, n, Ke)
+    return mask_dense(uX, uE, node_mask)
+
+
+def race_draw(p: Tensor, q: Tensor) -> Tensor:
+    """torch.multinomial(1) on CPU == argmax(p / q) with q ~ Exp(1) drawn from the same generator
+    state (verified in tests/golden/make_golden.py); first index wins ties."""
+    return (p / q).argmax(-1)
+
+
+def sample_discrete(probX: Tensor, probE: Tensor, node_mask: Tensor, qX: Tensor, qE: Tensor
+                    ) -> Tuple[Tensor, Tensor]:
+    """helpers.py:706-752 with explicit Exp(1) noise.  Returns class indices X (B,n), E (B,n,n)."""
+    B, n, Kx = probX.shape
+    Ke = probE.shape[-1]
+    pX = probX.clone()
+    pX[~node_mask] = 1 / Kx
+    Xs = race_draw(pX, qX) * node_mask.long()
+    pair = node_mask[:, :, None] & node_mask[:, None, :]
+    pE = probE.clone()
+    pE[~pair] = 1 / Ke
+    pE[:, torch.eye(n, dtype=torch.bool)] = 1 / Ke
+    Es = race_draw(pE, qE)
+    Es = torch.triu(Es, diagonal=1)
+    Es = Es + Es.transpose(1, 2)
+    Es = Es * pair.long()
+    return Xs, Es
+
+
+def one_hot_pair(Xs: Tensor, Es: Tensor, Kx: int, Ke: int) -> Tuple[Tensor, Tensor]:
+    return F.one_hot(Xs, Kx).float(), F.one_hot(Es, Ke).float()
+
+
+def sample_from_limit(x_limit: Tensor, e_limit: Tensor, node_mask: Tensor, qX: Tensor, qE: Tensor):
+    """helpers.py:831-859: z_T ~ limit dist per node/pair, upper triangle mirrored, .mask()."""
+    B, n = node_mask.shape
+    Kx, Ke = x_limit.numel(), e_limit.numel()
+    Xs = race_draw(x_limit[None, None, :].expand(B, n, -1), qX)
+    Es = race_draw(e_limit[None, None, None, :].expand(B, n, n, -1), qE)
+    X = F.one_hot(Xs, Kx).float()
+    E = F.one_hot(Es, Ke).float()
+    up = torch.triu(torch.ones(n, n), diagonal=1)[None, :, :, None]
+    E = E * up
+    E = E + E.transpose(1, 2)
+    return mask_dense(X, E, node_mask)
+
+
+def noise_probs(X: Tensor, E: Tensor, node_mask: Tensor, Qtb_x: Tensor, Qtb_e: Tensor):
+    """diffusion_abstract.py:253-257: probX = X @ Qbar_t.X, probE = E @ Qbar_t.E, .mask()."""
+    pX = X @ Qtb_x
+    pE = E @ Qtb_e.unsqueeze(1)
+    return mask_dense(pX, pE, node_mask)
+
+
+# --------------------------------------------------------------------------------------
+# a9-a12 denoiser forward (functional, reference state-dict key names)
+# --------------------------------------------------------------------------------------
+def _lin(sd, key, x):
+    return F.linear(x, sd[key + '.weight'], sd[key + '.bias'])
+
+
+def _stats4(T: Tensor, dims) -> Tensor:
+    """neuralnet/layers.py:15-47 Xtoy/Etoy pooled statistics [mean, min, max, std(unbiased)]."""
+    m = T.mean(dim=dims)
+    mi = T.amin(dim=dims)
+    ma = T.amax(dim=dims)
+    sd = T.std(dim=dims)
+    return torch.cat([m, mi, ma, sd], dim=-1)
+
+
+def node_edge_block(sd: Dict[str, Tensor], p: str, X, E, y, node_mask, n_head: int):
+    """neuralnet/layers.py:204-284 NodeEdgeBlock.forward (p = key prefix '...self_attn')."""
+    B, n, dx = X.shape
+    df = dx // n_head
+    xm = node_mask.to(X.dtype)[:, :, None]
+    em = xm[:, :, None, :] * xm[:, None, :, :]
+    Q = _lin(sd, p + '.q', X) * xm
+    K = _lin(sd, p + '.k', X) * xm
+    V = _lin(sd, p + '.v', X) * xm
+    Y = Q[:, :, None, :] * K[:, None, :, :] / math.sqrt(df)          # (B,i,j,dx)
+    E1 = _lin(sd, p + '.e_mul', E) * em
+    E2 = _lin(sd, p + '.e_add', E) * em
+    Y = Y * (E1 + 1) + E2
+    ye1 = _lin(sd, p + '.y_e_add', y)[:, None, None, :]
+    ye2 = _lin(sd, p + '.y_e_mul', y)[:, None, None, :]
+    newE = _lin(sd, p + '.e_out', ye1 + (ye2 + 1) * Y) * em
+    attn = F.softmax(Y, dim=2)                                       # over keys j, per channel, no mask
+    wV = (attn * V[:, None, :, :]).sum(dim=2)
+    yx1 = _lin(sd, p + '.y_x_add', y)[:, None, :]
+    yx2 = _lin(sd, p + '.y_x_mul', y)[:, None, :]
+    newX = _lin(sd, p + '.x_out', yx1 + (yx2 + 1) * wV) * xm
+    x_y = F.linear(_stats4(X, 1), sd[p + '.x_y.lin.weight'], sd[p + '.x_y.lin.bias'])
+    e_y = F.linear(_stats4(E, (1, 2)), sd[p + '.e_y.lin.weight'], sd[p + '.e_y.lin.bias'])
+    new_y = y + x_y + e_y
+    new_y = _lin(sd, p + '.y_out.2', F.relu(_lin(sd, p + '.y_out.0', new_y)))
+    return newX, newE, new_y
+
+
+def _ln(sd, key, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[key + '.weight'], sd[key + '.bias'], eps)
+
+
+def xey_layer(sd, p: str, X, E, y, node_mask, n_head: int):
+    """neuralnet/layers.py:330-361 XEyTransformerLayer.forward in eval mode (dropout = identity)."""
+    nX, nE, ny = node_edge_block(sd, p + '.self_attn', X, E, y, node_mask, n_head)
+    X = _ln(sd, p + '.normX1', X + nX)
+    E = _ln(sd, p + '.normE1', E + nE)
+    y = _ln(sd, p + '.norm_y1', y + ny)
+    X = _ln(sd, p + '.normX2', X + _lin(sd, p + '.linX2', F.relu(_lin(sd, p + '.linX1', X))))
+    E = _ln(sd, p + '.normE2', E + _lin(sd, p + '.linE2', F.relu(_lin(sd, p + '.linE1', E))))
+    y = _ln(sd, p + '.norm_y2', y + _lin(sd, p + '.lin_y2', F.relu(_lin(sd, p + '.lin_y1', y))))
+    return X, E, y
+
+
+def align_index(atom_map_numbers: Tensor, mol_assignments: Tensor) -> Tensor:
+    """Product->reactant alignment as a gather index (semantics of
+    transformer_model_with_y.py:506-555 with alignment_type='correct' and
+    utils/math_utils.py:3-44): src[b,r] = product node carrying the same atom-map number as
+    reactant-side node r, or -1 when r is not an atom-mapped reactant-side node."""
+    B, n = atom_map_numbers.shape
+    prod_id = mol_assignments.max(-1).values
+    is_prod = mol_assignments == prod_id[:, None]
+    am_prod = torch.where(is_prod, atom_map_numbers, torch.zeros_like(atom_map_numbers))
+    am_rct = torch.where(is_prod, torch.zeros_like(atom_map_numbers), atom_map_numbers)
+    src = torch.full((B, n), -1, dtype=torch.long)
+    for b in range(B):
+        pos = {int(a): i for i, a in enumerate(am_prod[b].tolist()) if a > 0}
+        for r, a in enumerate(am_rct[b].tolist()):
+            if a > 0:
+                assert a in pos, 'reactant atom-map number without a product partner'
+                src[b, r] = pos[a]
+        assert int((am_rct[b] > 0).sum()) == len(pos)   # transformer_model_with_y.py:523
+    return src
+
+
+def p_to_r_skip(X_o, E_o, X_in, E_in, src: Tensor, s1: float, s2: float, Kx: int, Ke: int):
+    """transformer_model_with_y.py:686-701."""
+    X_o = X_o.clone(); E_o = E_o.clone()
+    B, n = src.shape
+    for b in range(B):
+        sel = src[b] >= 0
+        idx = src[b][sel]
+        X_o[b, sel] += X_in[b, idx, :Kx] * s1
+        pair = sel[:, None] & sel[None, :]
+        Ea = E_in[b, :, :, :Ke][idx][:, idx]                          # (m,m,Ke)
+        E_o[b][pair] += Ea.reshape(-1, Ke) * s1
+        onehot0 = torch.zeros(Ke); onehot0[0] = 1.
+        E_o[b][~pair] += onehot0 * s2
+    return X_o, E_o
+
+
+def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n_head: int,
+                     out_dims: Tuple[int, int, int], atom_map_numbers=None, pos_encodings=None,
+                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = ''):
+    """transformer_model_with_y.py:620-713 (atom-map variant when pos_encodings is given) and
+    :74-111 (plain GraphTransformerWithY).  Returns un-masked logits (X, E, y)."""
+    Kx, Ke, Ky = out_dims
+    B, n = X.shape[:2]
+    X_in, E_in = X, E
+    def mlp_in(name, t):
+        return F.relu(_lin(sd, f'{prefix}{name}.2', F.relu(_lin(sd, f'{prefix}{name}.0', t))))
+    Eh = mlp_in('mlp_in_E', E)
+    Eh = (Eh + Eh.transpose(1, 2)) / 2
+    Xh, Eh = mask_dense(mlp_in('mlp_in_X', X), Eh, node_mask)       # encode_no_element on hidden feats
+    yh = mlp_in('mlp_in_y', y)
+    if pos_encodings is not None:
+        Xh = Xh + pos_encodings
+    for l in range(n_layers):
+        Xh, Eh, yh = xey_layer(sd, f'{prefix}tf_layers.{l}', Xh, Eh, yh, node_mask, n_head)
+    Xo = _lin(sd, prefix + 'mlp_out_X.2', F.relu(_lin(sd, prefix + 'mlp_out_X.0', Xh))) + X_in[..., :Kx]
+    Eo = _lin(sd, prefix + 'mlp_out_E.2', F.relu(_lin(sd, prefix + 'mlp_out_E.0', Eh))) + E_in[..., :Ke]
+    Eo = Eo * (~torch.eye(n, dtype=torch.bool))[None, :, :, None]
+    yo = yh[..., :Ky] + y[..., :Ky]
+    Eo = 0.5 * (Eo + Eo.transpose(1, 2))
+    if p_to_r_skip_connection:
+        src = align_index(atom_map_numbers, mol_assignments)
+        Xo, Eo = p_to_r_skip(Xo, Eo, X_in, E_in, src, float(sd[prefix + 'skip_scaling']),
+                             float(sd[prefix + 'skip_scaling_2']), Kx, Ke)
+    return Xo, Eo, yo
+
+
+# --------------------------------------------------------------------------------------
+# a16 one reverse step, a18-a19 ELBO terms
+# --------------------------------------------------------------------------------------
+def reverse_step(logits_X, logits_E, zt_X, zt_E, node_mask, tabs: Dict[str, Tensor], t: int,
+                 orig_X, orig_E, mask_x, mask_e, qX, qE, temp_x=1.0, temp_e=1.0):
+    """diffusion/sampling.py:82-86,165-178: log_softmax*temperature -> posterior -> draw -> apply_mask.
+    Returns (prob_X, prob_E, z_s X one-hot, z_s E one-hot)."""
+    B = zt_X.shape[0]
+    Kx, Ke = zt_X.shape[-1], zt_E.shape[-1]
+    lX = torch.log_softmax(logits_X, -1) * temp_x
+    lE = torch.log_softmax(logits_E, -1) * temp_e
+    ex = lambda T_, i: T_[i][None].expand(B, -1, -1)
+    pX, pE = posterior_probs(lX, lE, zt_X, zt_E, node_mask,
+                             ex(tabs['Qt_x'], t), ex(tabs['Qtb_x'], t - 1), ex(tabs['Qtb_x'], t),
+                             ex(tabs['Qt_e'], t), ex(tabs['Qtb_e'], t - 1), ex(tabs['Qtb_e'], t))
+    Xs, Es = sample_discrete(pX, pE, node_mask, qX, qE)
+    Xs1, Es1 = one_hot_pair(Xs, Es, Kx, Ke)
+    zX, zE = apply_mask(orig_X, orig_E, Xs1, Es1, mask_x, mask_e)
+    return pX, pE, zX, zE
+
+
+def posterior_true_or_pred(M: Tensor, M_t: Tensor, Qt: Tensor, Qsb: Tensor, log_space: bool = False) -> Tensor:
+    """helpers.py:754-783 compute_posterior_distribution. M, M_t: (B,N,K)."""
+    if not log_space:
+        num = (M_t @ Qt.transpose(-1, -2)) * (M @ Qsb)
+        return num / num.sum(-1, keepdim=True)
+    eps = 1e-30
+    Ml = torch.log_softmax(M, -1)
+    ln = torch.log(M_t @ Qt.transpose(-1, -2) + eps) + torch.log(torch.exp(Ml) @ Qsb + eps)
+    return ln - torch.logsumexp(ln, -1, keepdim=True)
+
+
+def kl_rows(target: Tensor, pred_log: Tensor) -> Tensor:
+    """F.kl_div(input=pred_log, target=target, reduction='none').sum(-1) (elbo.py:153-157)."""
+    return F.kl_div(pred_log, target, reduction='none').sum(-1)
+
+
+def compute_Lt(true_X, true_E, zt_X, zt_E, logits_X, logits_E, tabs, t_vec: Tensor, mask_x, mask_e, eps=1e-6,
+               log_space=False):
+    """diffusion/elbo.py:85-162.  t_vec (B,) integer step per graph.  Returns KL maps X (B,n), E (B,n,n)."""
+    B, n, Kx = true_X.shape
+    Ke = true_E.shape[-1]
+    ti = t_vec.long()
+    g = lambda name, idx: tabs[name][idx]
+    Qt_x, Qsb_x = g('Qt_x', ti), g('Qtb_x', ti - 1)
+    Qt_e, Qsb_e = g('Qt_e', ti), g('Qtb_e', ti - 1)
+    fl = lambda T_: T_.reshape(B, n * n, Ke)
+    qX = posterior_true_or_pred(true_X, zt_X, Qt_x, Qsb_x)
+    qE = posterior_true_or_pred(fl(true_E), fl(zt_E), Qt_e, Qsb_e).reshape(B, n, n, Ke)
+    qX, qE = apply_mask(true_X, true_E, qX, qE, mask_x, mask_e)
+    if not log_space:
+        pX = posterior_true_or_pred(F.softmax(logits_X, -1), zt_X, Qt_x, Qsb_x)
+        pE = posterior_true_or_pred(fl(F.softmax(logits_E, -1)), fl(zt_E), Qt_e, Qsb_e).reshape(B, n, n, Ke)
+        pX, pE = apply_mask(true_X, true_E, pX, pE, mask_x, mask_e)
+        return kl_rows(qX, (pX + eps).log()), kl_rows(qE, (pE + eps).log())
+    lpX = posterior_true_or_pred(logits_X, zt_X, Qt_x, Qsb_x, log_space=True)
+    lpE = posterior_true_or_pred(fl(logits_E), fl(zt_E), Qt_e, Qsb_e, log_space=True).reshape(B, n, n, Ke)
+    lpX, lpE = apply_mask(true_X, true_E, lpX, lpE, mask_x, mask_e, as_logits=True)
+    return kl_rows(qX, torch.log_softmax(lpX, -1)), kl_rows(qE, torch.log_softmax(lpE, -1))
+
+
+def kl_prior(true_X, true_E, tabs, T: int, mask_x, mask_e, eps=1e-6):
+    """diffusion/elbo.py:197-238 + helpers.py:115-137."""
+    B, n, Kx = true_X.shape
+    Ke = true_E.shape[-1]
+    pX = true_X @ tabs['Qtb_x'][T]
+    pE = true_E @ tabs['Qtb_e'][T]
+    lX = tabs['x_limit'][None, None, :].expand(B, n, -1)
+    lE = tabs['e_limit'][None, None, None, :].expand(B, n, n, -1)
+    lX, lE = apply_mask(true_X, true_E, lX, lE, mask_x, mask_e)
+    pX, pE = apply_mask(true_X, true_E, pX, pE, mask_x, mask_e)
+    return kl_rows(lX, (pX + eps).log()), kl_rows(lE, (pE + eps).log())
+
+
+def reconstruction_logp(true_X, true_E, logits_X, logits_E, mask_x, mask_e):
+    """diffusion/elbo.py:182-193 + helpers.py:139-151 (logits already apply_mask(as_logits=True)-ed here)."""
+    lX, lE = apply_mask(true_X, true_E, logits_X, logits_E, mask_x, mask_e, as_logits=True)
+    return (true_X * F.log_softmax(lX, -1)).sum(-1), (true_E * F.log_softmax(lE, -1)).sum(-1)
+
+
+def mean_without_masked(tX: Tensor, tE: Tensor, mask_x: Tensor, mask_e: Tensor, avg_over_batch=False,
+                        diffuse_nodes=True, diffuse_edges=True):
+    """helpers.py:59-106.  tX (B,n), tE (B,n,n); masks per node; E mask = outer product."""
+    mx = mask_x.to(tX.dtype)
+    me = (mask_e[:, :, None] & mask_e[:, None, :]).to(tE.dtype).flatten(1)
+    sX = tX * mx
+    sE = tE.flatten(1) * me
+    if avg_over_batch:
+        mX, mE = sX.sum() / mx.sum(), sE.sum() / me.sum()
+    else:
+        mX, mE = sX.sum(-1) / mx.sum(-1), sE.sum(-1) / me.sum(-1)
+    if diffuse_nodes and diffuse_edges:
+        return mX + mE
+    return mE if diffuse_edges else mX
+
+
+def ce_loss(logits_X, logits_E, true_X, true_E, mask_x, mask_e, lambda_E: float):
+    """helpers.py:153-191 with masks from apply_mask (diffusion_abstract.py:198-207)."""
+    me = (mask_e[:, :, None] & mask_e[:, None, :])
+    lX = F.cross_entropy(logits_X[mask_x], true_X[mask_x].argmax(-1), reduction='none')
+    lE = F.cross_entropy(logits_E[me], true_E[me].argmax(-1), reduction='none')
+    return lX, lE, lX.mean() + lambda_E * lE.mean()

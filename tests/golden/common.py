@@ -1,0 +1,52 @@
+"""Helpers shared by the golden-vector generator and the tests (no reference code in here)."""
+import numpy as np
+import torch
+
+from diffalign_amd.synthetic import ATOM_DECODER as ATOMS, BOND_DECODER as BONDS
+
+NOISE_BASE = 90_000
+
+
+def tiny_dims():
+    """BASELINE.json configs[0]: tiny 2-layer graph transformer."""
+    return dict(n_layers=2,
+                hidden_dims={'dx': 32, 'de': 8, 'dy': 8, 'n_head': 4, 'dim_ffX': 32, 'dim_ffE': 16, 'dim_ffy': 16},
+                hidden_mlp_dims={'X': 32, 'E': 16, 'y': 16})
+
+
+def init_state_dict(shapes, seed):
+    """Deterministic weights, one generator per parameter NAME (so variants that add/drop keys share the rest).
+    LayerNorm weights ~ 1 + 0.1 N, everything else ~ N(0,1)/sqrt(fan_in) (biases 0.1 N)."""
+    import zlib
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        g = torch.Generator().manual_seed(seed * 1_000_003 + zlib.crc32(k.encode()))
+        t = torch.randn(shp, generator=g)
+        if 'norm' in k and k.endswith('weight'):
+            t = 1 + 0.1 * t
+        elif k.startswith('skip_scaling'):
+            t = torch.ones(shp)
+        elif len(shp) == 2:
+            t = t / (shp[1] ** 0.5)
+        else:
+            t = 0.1 * t
+        sd[k] = t
+    return sd
+
+
+def counter_noise(shape, counter):
+    """Exp(1) race noise for the `counter`-th categorical draw call of a run."""
+    g = torch.Generator().manual_seed(NOISE_BASE + int(counter))
+    return torch.empty(tuple(shape)).exponential_(1.0, generator=g)
+
+
+def load(name):
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '.npz')
+    z = np.load(p, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def weights_of(z):
+    return {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('w::')}

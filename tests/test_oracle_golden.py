@@ -1,0 +1,156 @@
+"""Pins oracle/oracle.py (the CPU restatement) to the golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+from tests.golden.common import load, weights_of, counter_noise, ATOMS, BONDS
+
+KX, KE = len(ATOMS), len(BONDS)
+T = lambda a: torch.from_numpy(np.asarray(a))
+NM, EM = [28, 0], [4, 5, 6]
+
+
+def close(a, b, tol=1e-6):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol, err
+
+
+def test_transition_tables():
+    z = load('transitions')
+    a = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    m = O.marginal_tables(10, T(z['mar_x_marginals']), T(z['mar_e_marginals']), 1, NM, EM)
+    u = O.uniform_tables(10, KX, KE, 1, NM, EM)
+    name = dict(Qts_x='Qt_x', Qts_e='Qt_e', Qts_y='Qt_y', Qt_bars_x='Qtb_x', Qt_bars_e='Qtb_e', Qt_bars_y='Qtb_y',
+                x_limit='x_limit', e_limit='e_limit', y_limit='y_limit')
+    for tag, tab in (('abs10', a), ('mar10', m), ('uni10', u)):
+        for ref_name, mine in name.items():
+            close(tab[mine], z[f'{tag}_{ref_name}'], 1e-6)
+        # the reference's own property tests (tests/test_noise_schedule.py:95-143,237-290)
+        for k in ('Qt_x', 'Qt_e', 'Qtb_x', 'Qtb_e'):
+            assert (tab[k] >= 0).all()
+            close(tab[k].sum(-1), torch.ones_like(tab[k].sum(-1)), 1e-5)
+        if tag == 'abs10':
+            close(tab['Qtb_x'][0], torch.eye(KX), 1e-6)
+    for TT in (100, 500):
+        a = O.absorbing_tables(TT, KX, KE, 1, 27, 0, NM, EM)
+        sel = z[f'abs{TT}_sel'].tolist()
+        for ref_name in ('Qts_x', 'Qts_e', 'Qt_bars_x', 'Qt_bars_e'):
+            full = a[name[ref_name]]
+            close(full[sel], z[f'abs{TT}_{ref_name}_sel'], 1e-7)
+            close(full.double().sum((1, 2)), z[f'abs{TT}_{ref_name}_sum'], 1e-5)
+            w = torch.arange(full[0].numel()).reshape(full[0].shape).double()
+            close((full.double() * w).sum((1, 2)), z[f'abs{TT}_{ref_name}_wsum'], 1e-3)
+    t = T(z['abs10_gather_t'])[:, 0].long()
+    a = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    close(a['Qt_x'][t], z['abs10_gather_Qt_x']); close(a['Qtb_e'][t], z['abs10_gather_Qtb_e'])
+
+
+def test_container_mask_and_collapse():
+    z = load('container_masks')
+    X, E = O.mask_dense(T(z['in_X']), T(z['in_E']), T(z['node_mask']))
+    close(X, z['out_X'], 0); close(E, z['out_E'], 0)
+    Xi, Ei = O.collapse_dense(T(z['in_X']), T(z['in_E']), T(z['node_mask']))
+    assert np.array_equal(Xi.numpy(), z['col_X']) and np.array_equal(Ei.numpy(), z['col_E'])
+
+
+@pytest.mark.parametrize('tag', ['rag', 'full'])
+@pytest.mark.parametrize('mode', ['product_and_sn', 'atom_mapping', 'sn', 'product'])
+def test_free_masks(tag, mode):
+    z = load('container_masks')
+    X = F.one_hot(T(z[f'{tag}_X_idx']), KX).float()
+    mx, me = O.free_masks(X, T(z[f'{tag}_node_mask']), T(z[f'{tag}_am']), mode, suno_idx=28)
+    mX, mE = O.expand_masks(mx, me, KX, KE)
+    assert np.array_equal(mX[..., 0].numpy(), z[f'{tag}_{mode}_mask_X'])
+    assert np.array_equal(mE[..., 0].numpy(), z[f'{tag}_{mode}_mask_E'])
+
+
+def test_apply_mask_values():
+    z = load('container_masks')
+    X = F.one_hot(T(z['rag_X_idx']), KX).float(); E = F.one_hot(T(z['rag_E_idx']), KE).float()
+    nm = T(z['rag_node_mask'])
+    # the synthetic generator's dense encoding: padded rows / pairs / diagonal are class 0 one-hots
+    mx, me = O.free_masks(X, nm, T(z['rag_am']), 'product_and_sn', suno_idx=28)
+    for al in (0, 1):
+        rX, rE = O.apply_mask(X, E, T(z['apply_zX']), T(z['apply_zE']), mx, me, as_logits=bool(al))
+        close(rX, z[f'apply_{al}_X'], 0); close(rE, z[f'apply_{al}_E'], 0)
+
+
+def test_layer_tiny():
+    z = load('layer_tiny')
+    sd = weights_of(z)
+    X, E, y, nm = T(z['X']), T(z['E']), T(z['y']), T(z['node_mask'])
+    H = int(z['n_head'])
+    nX, nE, ny = O.node_edge_block(sd, 'self_attn', X, E, y, nm, H)
+    close(nX, z['blk_X'], 2e-5); close(nE, z['blk_E'], 2e-5); close(ny, z['blk_y'], 2e-5)
+    sd2 = {'L.' + k: v for k, v in sd.items()}
+    oX, oE, oy = O.xey_layer(sd2, 'L', X, E, y, nm, H)
+    close(oX, z['out_X'], 2e-5); close(oE, z['out_E'], 2e-5); close(oy, z['out_y'], 2e-5)
+
+
+def _model_inputs(z):
+    X = torch.cat([F.one_hot(T(z['X_idx']), KX).float(), T(z['X_extra'])], -1)
+    E = F.one_hot(T(z['E_idx']), KE).float()
+    return X, E, T(z['y_in']), T(z['node_mask']), T(z['am']), T(z['pos']), T(z['mol'])
+
+
+def test_model_tiny_all_variants():
+    z = load('model_tiny')
+    sd = weights_of(z)
+    X, E, y, nm, am, pos, mol = _model_inputs(z)
+    L, H = int(z['n_layers']), int(z['n_head'])
+    # plain / no-skip variants were generated with the same seed -> same weights minus skip params
+    r = O.denoiser_forward(sd, X, E, y, nm, L, H, (KX, KE, 1))
+    close(r[0], z['plain_X'], 5e-5); close(r[1], z['plain_E'], 5e-5); close(r[2], z['plain_y'], 5e-5)
+    r = O.denoiser_forward(sd, X, E, y, nm, L, H, (KX, KE, 1), am, pos, mol, False)
+    close(r[0], z['am_noskip_X'], 5e-5); close(r[1], z['am_noskip_E'], 5e-5)
+    r = O.denoiser_forward(sd, X, E, y, nm, L, H, (KX, KE, 1), am, pos, mol, True)
+    close(r[0], z['am_skip_X'], 5e-5); close(r[1], z['am_skip_E'], 5e-5); close(r[2], z['am_skip_y'], 5e-5)
+
+
+def test_model_full_dims_one_layer():
+    from tests.golden.common import init_state_dict
+    import ast
+    z = load('model_full1')
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(z['keys'], z['shapes'])}
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(z['n_params'])
+    sd = init_state_dict(shapes, seed=54)
+    X, E, y, nm, am, pos, mol = _model_inputs(z)
+    r = O.denoiser_forward(sd, X, E, y, nm, 1, 8, (KX, KE, 1), am, pos, mol, True)
+    close(r[0], z['out_X'], 2e-4); close(r[1], z['out_E'], 2e-4); close(r[2], z['out_y'], 2e-4)
+
+
+def _tables(fam, z):
+    if fam == 'abs':
+        return O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    g = torch.Generator().manual_seed(11)
+    xm = torch.rand(KX, generator=g); xm = xm / xm.sum()
+    em = torch.rand(KE, generator=g); em = em / em.sum()
+    return O.marginal_tables(10, xm, em, 1, NM, EM)
+
+
+@pytest.mark.parametrize('fam', ['abs', 'mar'])
+@pytest.mark.parametrize('t', [10, 5, 1])
+def test_posterior_and_draws(fam, t):
+    z = load('posterior_draws')
+    tabs = _tables(fam, z)
+    k = f'{fam}_t{t}_'
+    nm = T(z[f'{fam}_node_mask'])
+    B = nm.shape[0]
+    ztX = F.one_hot(T(z[k + 'zt_X']), KX).float(); ztE = F.one_hot(T(z[k + 'zt_E']), KE).float()
+    lX = torch.log_softmax(T(z[k + 'logit_X']), -1); lE = torch.log_softmax(T(z[k + 'logit_E']), -1)
+    ex = lambda name, i: tabs[name][i][None].expand(B, -1, -1)
+    pX, pE = O.posterior_probs(lX, lE, ztX, ztE, nm, ex('Qt_x', t), ex('Qtb_x', t - 1), ex('Qtb_x', t),
+                               ex('Qt_e', t), ex('Qtb_e', t - 1), ex('Qtb_e', t))
+    close(pX, z[k + 'prob_X'], 2e-6); close(pE, z[k + 'prob_E'], 2e-6)
+    # draws: bit-exact given the reference's probabilities and the same noise
+    c = int(z[k + 'noise_counter'])
+    n = nm.shape[1]
+    qX = counter_noise((B * n, KX), c).reshape(B, n, KX)
+    qE = counter_noise((B * n * n, KE), c + 1).reshape(B, n, n, KE)
+    Xs, Es = O.sample_discrete(T(z[k + 'prob_X']), T(z[k + 'prob_E']), nm, qX, qE)
+    assert np.array_equal(Xs.numpy(), z[k + 'zs_X']) and np.array_equal(Es.numpy(), z[k + 'zs_E'])
