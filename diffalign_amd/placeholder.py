@@ -1,0 +1,106 @@
+"""Dense graph container with the reference's PlaceHolder interface (diffalign/utils/placeholder.py:21-179).
+Masking runs in the HIP library (da_mask_dense / da_collapse)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, fields
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def encode_no_element(A: torch.Tensor) -> torch.Tensor:
+    """Same contract as diffalign/utils/placeholder.py:9-18 (in place, returns A)."""
+    assert A.dim() >= 3
+    if A.shape[-1] == 0:
+        return A
+    flat = A.reshape(-1, A.shape[-1])
+    ones = torch.ones(flat.shape[0], dtype=torch.bool, device=A.device)
+    if not flat.is_contiguous() or flat.data_ptr() != A.data_ptr():
+        raise L.DiffAlignHipError('encode_no_element needs a contiguous tensor')
+    L.check(L.lib().da_mask_dense(L.ptr(flat, torch.float32), L.ptr(None), L.ptr(L.as_u8(ones)), C.c_int(1),
+                                  C.c_int(flat.shape[0]), C.c_int(flat.shape[1]), C.c_int(0), L.stream()),
+            'da_mask_dense')
+    return A
+
+
+@dataclass
+class PlaceHolder:
+    X: torch.Tensor
+    E: torch.Tensor
+    y: torch.Tensor
+    node_mask: Optional[torch.Tensor] = None
+    atom_map_numbers: Optional[torch.Tensor] = None
+    mol_assignments: Optional[torch.Tensor] = None
+
+    def _apply(self, fn):
+        return PlaceHolder(**{f.name: fn(getattr(self, f.name)) if isinstance(getattr(self, f.name), torch.Tensor)
+                              else None for f in fields(self)})
+
+    def _apply_inplace(self, fn):
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if isinstance(v, torch.Tensor):
+                setattr(self, f.name, fn(v))
+        return self
+
+    def type_as(self, x):
+        return self._apply_inplace(lambda t: t.type_as(x))
+
+    def to_device(self, device):
+        return self._apply_inplace(lambda t: t.to(device))
+
+    def to_cpu(self):
+        return self._apply_inplace(lambda t: t.detach().cpu())
+
+    def flatten(self, start_dim, end_dim):
+        return self._apply(lambda t: t.flatten(start_dim=start_dim, end_dim=end_dim))
+
+    def select_subset(self, selection):
+        return self._apply(lambda t: t.clone()[selection])
+
+    def slice_by_idx(self, idx):
+        return self._apply(lambda t: t.clone()[:idx])
+
+    def subset_by_idx(self, start_idx, end_idx):
+        return self._apply(lambda t: t[start_idx:end_idx].clone())
+
+    def get_new_object(self, **kwargs):
+        """New PlaceHolder with the given fields replaced; every tensor field cloned (placeholder.py:72-79)."""
+        return PlaceHolder(**{f.name: kwargs[f.name].clone() if isinstance(kwargs.get(f.name), torch.Tensor)
+                              else getattr(self, f.name).clone() if isinstance(getattr(self, f.name), torch.Tensor)
+                              else None for f in fields(self)})
+
+    def mask(self, node_mask=None, collapse=False):
+        """placeholder.py:81-102, on the GPU."""
+        if node_mask is None:
+            node_mask = self.node_mask
+        assert node_mask is not None, 'node_mask is None.'
+        B, n = node_mask.shape
+        nm = L.as_u8(node_mask)
+        if collapse:
+            X = self.X.contiguous().float(); E = self.E.contiguous().float()
+            Xi = torch.empty(B, n, dtype=torch.int64, device=X.device)
+            Ei = torch.empty(B, n, n, dtype=torch.int64, device=X.device)
+            L.check(L.lib().da_collapse(L.ptr(X, torch.float32), L.ptr(E, torch.float32), L.ptr(nm), L.ptr(Xi), L.ptr(Ei),
+                                        C.c_int(B), C.c_int(n), C.c_int(X.shape[-1]), C.c_int(E.shape[-1]), L.stream()),
+                    'da_collapse')
+            self.X, self.E = Xi, Ei
+        else:
+            # the reference multiplies out of place and then writes in place on the product
+            self.X = self.X.float().clone() if self.X.dtype != torch.float32 or not self.X.is_contiguous() else self.X.clone()
+            self.E = self.E.float().clone() if self.E.dtype != torch.float32 or not self.E.is_contiguous() else self.E.clone()
+            self.X = self.X.contiguous(); self.E = self.E.contiguous()
+            L.check(L.lib().da_mask_dense(L.ptr(self.X, torch.float32), L.ptr(self.E, torch.float32), L.ptr(nm), C.c_int(B),
+                                          C.c_int(n), C.c_int(self.X.shape[-1]), C.c_int(self.E.shape[-1]), L.stream()),
+                    'da_mask_dense')
+        return self
+
+    def serialize(self):
+        return {f.name: getattr(self, f.name).detach().cpu().numpy().tolist() for f in fields(self)}
+
+    @classmethod
+    def deserialize(cls, data: dict) -> 'PlaceHolder':
+        return cls(**{k: torch.tensor(v) if v is not None else None for k, v in data.items()})
