@@ -1,0 +1,223 @@
+// Edge input / output stages of the denoiser (neuralnet/transformer_model_with_y.py:657-661 and :672-704).
+// Same machinery as the fused layer: transposed GEMM chain through accumulators, weights as pre-packed A fragments in
+// LDS, one wave per query row (b,i), 32-pair tiles; both orientations (i,j) and (j,i) are evaluated by the same wave
+// so the symmetrisation needs no second pass over the edge tensor.
+#include "mfma_util.h"
+
+template <int DE, int HE>
+struct EdgeIoCfg {
+  static constexpr int HT = HE / 32, KSH = HE / 16, MT = DE / 32, KS1 = DE / 16;
+  // input stage:  W0 (HE x 16pad) natural-k fragments [HT], W1 (DE x HE) C-order fragments [MT*KSH]; params b0[HE] b1[DE]
+  static constexpr int IN_FR = HT + MT * KSH;
+  static constexpr int IN_PAR = HE + DE;
+  static constexpr size_t IN_BYTES = (size_t)IN_FR * 1024 + IN_PAR * 4;
+  // output stage: W0 (HE x DE) C-order fragments [HT*KS1], W1 (32pad x HE) C-order fragments [KSH]; params b0[HE] b1[32]
+  static constexpr int OUT_FR = HT * KS1 + KSH;
+  static constexpr int OUT_PAR = HE + 32;
+  static constexpr size_t OUT_BYTES = (size_t)OUT_FR * 1024 + OUT_PAR * 4;
+};
+
+__device__ __forceinline__ void load_bias16(f32x16& acc, const float* p, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 bv = *reinterpret_cast<const float4*>(p + 8 * g + 4 * h);
+    acc[4 * g + 0] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+  }
+}
+
+// ---- input stage: E_h = encode_no_element(mask(sym(mlp_in_E(E)))) as bf16 ---------------------------------------
+template <int DE, int HE>
+__device__ __forceinline__ void mlp_in_chain(const float* __restrict__ src, int de_in, int h, int lane, const uint4* sW0,
+                                             const uint4* sW1, const float* sP, f32x16 (&o)[DE / 32]) {
+  using C = EdgeIoCfg<DE, HE>;
+  float xv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xv[j] = (8 * h + j < de_in) ? src[8 * h + j] : 0.f;
+  const uint4 xu = {pack_bf16(xv[0], xv[1]), pack_bf16(xv[2], xv[3]), pack_bf16(xv[4], xv[5]), pack_bf16(xv[6], xv[7])};
+  const bf16x8 xb = frag_from_u4(xu);
+  bf16x8 hB[C::KSH];
+#pragma unroll
+  for (int ht = 0; ht < C::HT; ++ht) {
+    f32x16 hacc;
+    load_bias16(hacc, sP + 32 * ht, h);
+    hacc = mfma32(lds_frag(sW0, ht, lane), xb, hacc);
+#pragma unroll
+    for (int i2 = 0; i2 < 16; ++i2) hacc[i2] = fmaxf(hacc[i2], 0.f);
+    hB[2 * ht] = pack_acc(hacc, 0); hB[2 * ht + 1] = pack_acc(hacc, 1);
+  }
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    load_bias16(o[mt], sP + HE + 32 * mt, h);
+#pragma unroll
+    for (int s = 0; s < C::KSH; ++s) o[mt] = mfma32(lds_frag(sW1, mt * C::KSH + s, lane), hB[s], o[mt]);
+#pragma unroll
+    for (int i2 = 0; i2 < 16; ++i2) o[mt][i2] = fmaxf(o[mt][i2], 0.f);
+  }
+}
+
+template <int DE, int HE>
+__global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in, int de_in, const uint8_t* __restrict__ nm,
+                                                 const uint4* __restrict__ blob, bf16_t* __restrict__ E_out, int B, int n) {
+  using C = EdgeIoCfg<DE, HE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sW = reinterpret_cast<uint4*>(smem);
+  for (int t = threadIdx.x; t < (int)(C::IN_BYTES / 16); t += 256) sW[t] = blob[t];
+  __syncthreads();
+  const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * 64;
+  const float* sP = reinterpret_cast<const float*>(sW + C::IN_FR * 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int NT = (n + 31) / 32, R = B * n;
+  for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    const int b = row / n, i = row - b * n;
+    const bool mi = nm[row] != 0;
+    for (int jt = 0; jt < NT; ++jt) {
+      const int jl = jt * 32 + r; const bool jvalid = jl < n; const int jc = jvalid ? jl : n - 1;
+      f32x16 o[C::MT], om[C::MT];
+      mlp_in_chain<DE, HE>(E_in + ((size_t)row * n + jc) * de_in, de_in, h, lane, sW0, sW1, sP, o);
+      mlp_in_chain<DE, HE>(E_in + (((size_t)b * n + jc) * n + i) * de_in, de_in, h, lane, sW0, sW1, sP, om);
+      const float pm = (mi && jvalid && nm[b * n + jc] && jc != i) ? 1.f : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) { const float v = (o[mt][i2] + om[mt][i2]) * 0.5f * pm; o[mt][i2] = v; sum += v; }
+      sum = xhalf_sum(sum);
+      if (sum == 0.f && h == 0) o[0][0] = 1.f;        // encode_no_element on the hidden features
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) {
+        const int mt = u >> 1, g0 = 2 * (u & 1);
+        uint4 st = {pack_bf16(o[mt][4 * g0 + 0], o[mt][4 * g0 + 1]), pack_bf16(o[mt][4 * g0 + 2], o[mt][4 * g0 + 3]),
+                    pack_bf16(o[mt][4 * g0 + 4], o[mt][4 * g0 + 5]), pack_bf16(o[mt][4 * g0 + 6], o[mt][4 * g0 + 7])};
+        row16_to_corder(st);
+        if (jvalid) *reinterpret_cast<uint4*>(E_out + ((size_t)row * n + jl) * DE + 16 * u + 8 * h) = st;
+      }
+    }
+  }
+}
+
+// ---- output stage: logits E_o = sym((mlp_out_E(E_h) + E_in[..., :Ke]) * offdiag) (+ product->reactant skip) ------
+template <int DE, int HE>
+__device__ __forceinline__ void mlp_out_chain(const bf16_t* __restrict__ erow, int h, int lane, const uint4* sW0,
+                                              const uint4* sW1, const float* sP, f32x16& o) {
+  using C = EdgeIoCfg<DE, HE>;
+  bf16x8 eB[C::KS1];
+#pragma unroll
+  for (int u = 0; u < C::KS1; ++u) {
+    uint4 v = *reinterpret_cast<const uint4*>(erow + 16 * u + 8 * h);
+    row16_to_corder(v);
+    eB[u] = frag_from_u4(v);
+  }
+  bf16x8 hB[C::KSH];
+#pragma unroll
+  for (int ht = 0; ht < C::HT; ++ht) {
+    f32x16 hacc;
+    load_bias16(hacc, sP + 32 * ht, h);
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s) hacc = mfma32(lds_frag(sW0, ht * C::KS1 + s, lane), eB[s], hacc);
+#pragma unroll
+    for (int i2 = 0; i2 < 16; ++i2) hacc[i2] = fmaxf(hacc[i2], 0.f);
+    hB[2 * ht] = pack_acc(hacc, 0); hB[2 * ht + 1] = pack_acc(hacc, 1);
+  }
+  load_bias16(o, sP + HE, h);
+#pragma unroll
+  for (int s = 0; s < C::KSH; ++s) o = mfma32(lds_frag(sW1, s, lane), hB[s], o);
+}
+
+template <int DE, int HE>
+__global__ void __launch_bounds__(256) k_edge_out(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
+                                                  const uint4* __restrict__ blob, const int* __restrict__ src,
+                                                  const float* __restrict__ s1p, const float* __restrict__ s2p,
+                                                  float* __restrict__ E_o, int B, int n, int Ke) {
+  using C = EdgeIoCfg<DE, HE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sW = reinterpret_cast<uint4*>(smem);
+  for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += 256) sW[t] = blob[t];
+  __syncthreads();
+  const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * C::KS1 * 64;
+  const float* sP = reinterpret_cast<const float*>(sW + C::OUT_FR * 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int NT = (n + 31) / 32, R = B * n;
+  const float s1 = src ? s1p[0] : 0.f, s2 = src ? s2p[0] : 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    const int b = row / n, i = row - b * n;
+    const int si = src ? src[row] : -1;
+    for (int jt = 0; jt < NT; ++jt) {
+      const int jl = jt * 32 + r; const bool jvalid = jl < n; const int jc = jvalid ? jl : n - 1;
+      f32x16 o, om;
+      mlp_out_chain<DE, HE>(E_h + ((size_t)row * n + jc) * DE, h, lane, sW0, sW1, sP, o);
+      mlp_out_chain<DE, HE>(E_h + (((size_t)b * n + jc) * n + i) * DE, h, lane, sW0, sW1, sP, om);
+      if (!jvalid) continue;
+      const float* ein = E_in + ((size_t)row * n + jl) * de_in;
+      const float* einm = E_in + (((size_t)b * n + jl) * n + i) * de_in;
+      const int sj = src ? src[b * n + jl] : -1;
+      const bool aligned = si >= 0 && sj >= 0;
+      const float* ealn = aligned ? E_in + (((size_t)b * n + si) * n + sj) * de_in : nullptr;
+      float* dst = E_o + ((size_t)row * n + jl) * Ke;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * h + e;                      // class index = accumulator row crow(e,h), e<4
+        if (c >= Ke) continue;
+        float v = (jl == i) ? 0.f : 0.5f * ((o[e] + ein[c]) + (om[e] + einm[c]));
+        if (src) v += aligned ? s1 * ealn[c] : (c == 0 ? s2 : 0.f);
+        dst[c] = v;
+      }
+    }
+  }
+}
+
+// ===================================================================================================
+static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
+
+template <int DE, int HE>
+static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s) {
+  using C = EdgeIoCfg<DE, HE>;
+  k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n);
+  return DA_OK;
+}
+template <int DE, int HE>
+static int launch_out(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* s1,
+                      const float* s2, float* E_o, int B, int n, int Ke, hipStream_t s) {
+  using C = EdgeIoCfg<DE, HE>;
+  k_edge_out<DE, HE><<<io_grid(B * n), 256, C::OUT_BYTES, s>>>((const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, s1, s2, E_o, B, n, Ke);
+  return DA_OK;
+}
+
+extern "C" {
+
+long long da_edge_in_blob_bytes(int de, int he) {
+  if (de == 64 && he == 128) return (long long)EdgeIoCfg<64, 128>::IN_BYTES;
+  if (de == 32 && he == 32) return (long long)EdgeIoCfg<32, 32>::IN_BYTES;
+  return -1;
+}
+long long da_edge_out_blob_bytes(int de, int he) {
+  if (de == 64 && he == 128) return (long long)EdgeIoCfg<64, 128>::OUT_BYTES;
+  if (de == 32 && he == 32) return (long long)EdgeIoCfg<32, 32>::OUT_BYTES;
+  return -1;
+}
+
+// E_h(bf16) = encode_no_element(mask(sym(mlp_in_E(E))))     transformer_model_with_y.py:657-661
+int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
+               int he, void* stream) {
+  DA_CHECK_ARG(de_in >= 1 && de_in <= 16, "da_edge_in: input edge feature width %d not in 1..16", de_in);
+  if (B == 0 || n == 0) return DA_OK;
+  if (de == 64 && he == 128) launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream);
+  else if (de == 32 && he == 32) launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream);
+  else { da_set_error("da_edge_in: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_in");
+  return DA_OK;
+}
+
+// E logits = sym((mlp_out_E(E_h)+E_in[..., :ke])*offdiag) [+ skip]   transformer_model_with_y.py:672-704
+int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
+                const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream) {
+  DA_CHECK_ARG(ke >= 1 && ke <= 8 && ke <= de_in, "da_edge_out: ke=%d must be in 1..8 and <= input width", ke);
+  DA_CHECK_ARG(!(src && (!skip1 || !skip2)), "da_edge_out: skip connection needs both scale pointers");
+  if (B == 0 || n == 0) return DA_OK;
+  if (de == 64 && he == 128) launch_out<64, 128>(E_h, E_in, de_in, blob, src, skip1, skip2, E_logits, B, n, ke, (hipStream_t)stream);
+  else if (de == 32 && he == 32) launch_out<32, 32>(E_h, E_in, de_in, blob, src, skip1, skip2, E_logits, B, n, ke, (hipStream_t)stream);
+  else { da_set_error("da_edge_out: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_out");
+  return DA_OK;
+}
+
+}  // extern "C"

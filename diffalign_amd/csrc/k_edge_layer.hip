@@ -1,0 +1,418 @@
+// Fused node-edge attention layer, edge side (the ~85 % of the reference's step time).
+//
+// Replaces, for one XEyTransformerLayer (neuralnet/layers.py:204-284 NodeEdgeBlock + :330-361 the E branch):
+//   E1=e_mul(E)*m, E2=e_add(E)*m, Y=(Q_i*K_j/sqrt(df))*(E1+1)+E2, newE=e_out(ye1+(ye2+1)*Y)*m,
+//   attn=softmax_j(Y) per channel WITHOUT key mask, wV=sum_j attn*V_j, newX_in = yx1+(yx2+1)*wV,
+//   E' = LN2(Em + linE2(relu(linE1(Em)))),  Em = LN1(E + newE)
+// in ONE pass over the (B,n,n,de) edge tensor: each 64-B..128-B edge row is read once and written once (bf16).
+//
+// Structure (MI355X): persistent workgroups, all layer weights resident in LDS as pre-packed MFMA fragments
+// (132 KiB at full dims), every wave owns whole query rows (b,i) and walks the key axis in 32-pair tiles.
+// Per tile and 32-channel block:  GEMM1 (pairs x channels, softmax-friendly: key index in registers, channel on the
+// lane) -> elementwise Y, online softmax, FiLM -> in-register transpose by an identity MFMA -> GEMM2 accumulates
+// newE^T (channels in registers, pair on the lane) -> LN1 -> FFN chained through accumulators -> LN2 -> store.
+// No LDS traffic for activations, no barriers in the main loop.
+#include "mfma_util.h"
+
+template <int DE, int DX, int DFF>
+struct EdgeCfg {
+  static constexpr int NCB = DX / 32;
+  static constexpr int KS1 = DE / 16;
+  static constexpr int MT = DE / 32;
+  static constexpr int HT = DFF / 32;
+  static constexpr int KSF = DFF / 16;
+  static constexpr int W1_FR = NCB * 2 * KS1;
+  static constexpr int WO_FR = NCB * MT * 2;
+  static constexpr int F1_FR = HT * KS1;
+  static constexpr int F2_FR = MT * KSF;
+  static constexpr int N_FR = W1_FR + WO_FR + F1_FR + F2_FR;
+  // fp32 params after the fragments: bm1[DX] ba[DX] ln1g[DE] ln1b[DE] bf1[DFF] bf2[DE] ln2g[DE] ln2b[DE]
+  static constexpr int P_BM1 = 0, P_BA = DX, P_LN1G = 2 * DX, P_LN1B = 2 * DX + DE, P_BF1 = 2 * DX + 2 * DE,
+                       P_BF2 = 2 * DX + 2 * DE + DFF, P_LN2G = 2 * DX + 3 * DE + DFF, P_LN2B = 2 * DX + 4 * DE + DFF,
+                       N_PAR = 2 * DX + 5 * DE + DFF;
+  static constexpr size_t BLOB_BYTES = (size_t)N_FR * 1024 + (size_t)N_PAR * 4;
+  static constexpr size_t STATE_BYTES_PER_WAVE = (size_t)NCB * 3 * 64 * 4;
+};
+
+struct EdgeLayerArgs {
+  const bf16_t* E_in;     // (B,n,n,DE) bf16
+  bf16_t* E_out;          // (B,n,n,DE) bf16
+  const float* Q;         // (B*n, ldq) q(X)*mask
+  int ldq;
+  const uint4* KV;        // fragment layout, see k_kv_pack
+  const uint8_t* node_mask;
+  const float* ye2p1;     // (B,DX)  1 + y_e_mul(y)
+  const float* ebias;     // (B,DE)  e_out.bias + e_out.W @ y_e_add(y)
+  const float* yx1;       // (B,DX)  y_x_add(y)
+  const float* yx2p1;     // (B,DX)  1 + y_x_mul(y)
+  float* newX_in;         // (B,n,DX) = yx1 + yx2p1 * wV   (input of x_out)
+  const uint4* blob;      // packed layer weights (EdgeCfg layout)
+  float qscale;           // 1/sqrt(df)
+  int B, n;
+};
+
+template <int DE, int DX, int DFF, int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
+  using C = EdgeCfg<DE, DX, DFF>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sW = reinterpret_cast<uint4*>(smem);
+  {
+    const int n16 = (int)(C::BLOB_BYTES / 16);
+    for (int t = threadIdx.x; t < n16; t += NTHREADS) sW[t] = a.blob[t];
+  }
+  __syncthreads();
+  const uint4* sW1 = sW;
+  const uint4* sWO = sW1 + C::W1_FR * 64;
+  const uint4* sF1 = sWO + C::WO_FR * 64;
+  const uint4* sF2 = sF1 + C::F1_FR * 64;
+  const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
+  // per-wave online-softmax state (running max, sum, weighted sum) per channel block, lane-private slots
+  float* sS = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (C::NCB * 3 * 64) + (threadIdx.x & 63);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int NW = NTHREADS / 64;
+  const int n = a.n;
+  const int NT = (n + 31) / 32;
+  const int R = a.B * n;
+
+  const bf16x8 id0 = ident_frag(0, r, h), id1 = ident_frag(1, r, h);
+
+  // XCD-aware persistent row walk: blocks with equal blockIdx%8 share an XCD (L2); give each XCD one contiguous
+  // chunk of rows so a graph's K/V fragments and Q rows stay in that L2.
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int chunk = (R + 7) / 8;
+  const int row_begin = xcd * chunk, row_end = min(R, row_begin + chunk);
+
+  for (int row = row_begin + bi * NW + wave; row < row_end; row += bpx * NW) {
+    const int b = row / n, i = row - b * n;
+    const bool mi = a.node_mask[row] != 0;
+#pragma unroll
+    for (int cb = 0; cb < C::NCB; ++cb) {
+      sS[(cb * 3 + 0) * 64] = -INFINITY; sS[(cb * 3 + 1) * 64] = 0.f; sS[(cb * 3 + 2) * 64] = 0.f;
+    }
+    const float* Qrow = a.Q + (size_t)row * a.ldq + r;
+    const float* F2row = a.ye2p1 + (size_t)b * DX + r;
+    const bf16_t* Erow = a.E_in + (size_t)row * n * DE;
+    bf16_t* Orow = a.E_out + (size_t)row * n * DE;
+
+    for (int jt = 0; jt < NT; ++jt) {
+      const int jl = jt * 32 + r;
+      const bool jvalid = jl < n;
+      const int jc = jvalid ? jl : n - 1;
+      // ---- E tile: this lane's pair row, 16 B per k-step, then to C-order
+      uint4 eraw[C::KS1];
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jc * DE + 16 * u + 8 * h);
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) row16_to_corder(eraw[u]);
+      const bool mj = jvalid && (a.node_mask[b * n + jc] != 0);
+      const unsigned nmbits = (unsigned)__ballot(mj) >> (4 * h);       // bit p: key row p of this tile is a real node
+      const unsigned vbits = (unsigned)__ballot(jvalid) >> (4 * h);    // bit p: key row p exists (j < n)
+      const float pm = (mi && mj) ? 1.f : 0.f;                          // pair mask of this lane's column
+
+      f32x16 acc2[C::MT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) acc2[mt] = splat16(0.f);
+
+      const uint4* kvt = a.KV + ((size_t)(b * NT + jt) * C::NCB) * 4 * 64;
+#pragma unroll 1
+      for (int cb = 0; cb < C::NCB; ++cb) {
+        const float qc = Qrow[32 * cb] * a.qscale, f2c = F2row[32 * cb];
+        const float sm_m = sS[(cb * 3 + 0) * 64], sm_l = sS[(cb * 3 + 1) * 64], sm_a = sS[(cb * 3 + 2) * 64];
+        const uint4 kf0 = kvt[(cb * 4 + 0) * 64 + lane], kf1 = kvt[(cb * 4 + 1) * 64 + lane];
+        const uint4 vf0 = kvt[(cb * 4 + 2) * 64 + lane], vf1 = kvt[(cb * 4 + 3) * 64 + lane];
+        f32x16 e1 = splat16(sP[C::P_BM1 + 32 * cb + r]);
+        f32x16 e2 = splat16(sP[C::P_BA + 32 * cb + r]);
+#pragma unroll
+        for (int s = 0; s < C::KS1; ++s) {
+          e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
+          e2 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
+        }
+        const unsigned kk[8] = {kf0.x, kf0.y, kf0.z, kf0.w, kf1.x, kf1.y, kf1.z, kf1.w};
+        const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) {
+          const int bit = (i2 & 3) + 8 * (i2 >> 2);
+          const float kval = (i2 & 1) ? bf16_hi(kk[i2 >> 1]) : bf16_lo(kk[i2 >> 1]);
+          float y = fmaf(qc * kval, e1[i2], e2[i2]);
+          y = (mi && ((nmbits >> bit) & 1u)) ? y : 0.f;
+          e1[i2] = y;
+          tmax = fmaxf(tmax, ((vbits >> bit) & 1u) ? y : -INFINITY);
+        }
+        const float mnew = fmaxf(sm_m, tmax);
+        const float mref = (mnew == -INFINITY) ? 0.f : mnew;
+        const float sc = __expf(sm_m - mref);
+        float psum = 0.f, pv = 0.f;
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) {
+          const int bit = (i2 & 3) + 8 * (i2 >> 2);
+          const float vval = (i2 & 1) ? bf16_hi(vv[i2 >> 1]) : bf16_lo(vv[i2 >> 1]);
+          const float p = ((vbits >> bit) & 1u) ? __expf(e1[i2] - mref) : 0.f;
+          psum += p;
+          pv = fmaf(p, vval, pv);
+          e1[i2] *= f2c;                                             // FiLM multiplicative part
+        }
+        sS[(cb * 3 + 0) * 64] = mnew;
+        sS[(cb * 3 + 1) * 64] = sm_l * sc + psum;
+        sS[(cb * 3 + 2) * 64] = sm_a * sc + pv;
+        // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
+        f32x16 zt = splat16(0.f);
+        zt = mfma32(pack_acc(e1, 0), id0, zt);
+        zt = mfma32(pack_acc(e1, 1), id1, zt);
+        const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
+          acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 1, lane), zb1, acc2[mt]);
+        }
+      }
+      // ---- epilogue of the tile: newE^T + bias, pair mask, residual, LN1
+      float sum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bias = *reinterpret_cast<const float4*>(a.ebias + (size_t)b * DE + 32 * mt + 8 * g + 4 * h);
+          const uint4& er = eraw[2 * mt + (g >> 1)];
+          const unsigned d0 = (g & 1) ? er.z : er.x, d1 = (g & 1) ? er.w : er.y;
+          const float ev[4] = {bf16_lo(d0), bf16_hi(d0), bf16_lo(d1), bf16_hi(d1)};
+          const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = ev[e] + pm * (acc2[mt][4 * g + e] + bb[e]);
+            acc2[mt][4 * g + e] = x;
+            sum += x;
+          }
+        }
+      }
+      const float mean1 = xhalf_sum(sum) * (1.f / DE);
+      float vs = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) { const float d = acc2[mt][i2] - mean1; vs = fmaf(d, d, vs); }
+      const float rstd1 = rsqrtf(xhalf_sum(vs) * (1.f / DE) + 1e-5f);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 gg = *reinterpret_cast<const float4*>(sP + C::P_LN1G + 32 * mt + 8 * g + 4 * h);
+          const float4 be = *reinterpret_cast<const float4*>(sP + C::P_LN1B + 32 * mt + 8 * g + 4 * h);
+          const float g4[4] = {gg.x, gg.y, gg.z, gg.w}, b4[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2[mt][4 * g + e] = fmaf((acc2[mt][4 * g + e] - mean1) * rstd1, g4[e], b4[e]);
+        }
+      }
+      // ---- FFN chained through accumulators:  H^T = relu(W1 Em^T + b1),  O^T = W2 H^T + b2
+      bf16x8 emB[C::KS1];
+#pragma unroll
+      for (int s = 0; s < C::KS1; ++s) emB[s] = pack_acc(acc2[s >> 1], s & 1);
+      bf16x8 hB[C::KSF];
+#pragma unroll
+      for (int ht = 0; ht < C::HT; ++ht) {
+        f32x16 hacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(sP + C::P_BF1 + 32 * ht + 8 * g + 4 * h);
+          hacc[4 * g + 0] = bv.x; hacc[4 * g + 1] = bv.y; hacc[4 * g + 2] = bv.z; hacc[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < C::KS1; ++s) hacc = mfma32(lds_frag(sF1, ht * C::KS1 + s, lane), emB[s], hacc);
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) hacc[i2] = fmaxf(hacc[i2], 0.f);
+        hB[2 * ht + 0] = pack_acc(hacc, 0);
+        hB[2 * ht + 1] = pack_acc(hacc, 1);
+      }
+      float sum2 = 0.f;
+      f32x16 o[C::MT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(sP + C::P_BF2 + 32 * mt + 8 * g + 4 * h);
+          o[mt][4 * g + 0] = bv.x; o[mt][4 * g + 1] = bv.y; o[mt][4 * g + 2] = bv.z; o[mt][4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < C::KSF; ++s) o[mt] = mfma32(lds_frag(sF2, mt * C::KSF + s, lane), hB[s], o[mt]);
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) { o[mt][i2] += acc2[mt][i2]; sum2 += o[mt][i2]; }
+      }
+      const float mean2 = xhalf_sum(sum2) * (1.f / DE);
+      float vs2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) { const float d = o[mt][i2] - mean2; vs2 = fmaf(d, d, vs2); }
+      const float rstd2 = rsqrtf(xhalf_sum(vs2) * (1.f / DE) + 1e-5f);
+      // ---- LN2, pack to bf16 (C-order), back to row order, 16-byte stores
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) {
+        const int mt = u >> 1;
+        unsigned d[4];
+#pragma unroll
+        for (int gg2 = 0; gg2 < 2; ++gg2) {
+          const int g = 2 * (u & 1) + gg2;
+          const float4 gv = *reinterpret_cast<const float4*>(sP + C::P_LN2G + 32 * mt + 8 * g + 4 * h);
+          const float4 bv = *reinterpret_cast<const float4*>(sP + C::P_LN2B + 32 * mt + 8 * g + 4 * h);
+          const float y0 = fmaf((o[mt][4 * g + 0] - mean2) * rstd2, gv.x, bv.x);
+          const float y1 = fmaf((o[mt][4 * g + 1] - mean2) * rstd2, gv.y, bv.y);
+          const float y2 = fmaf((o[mt][4 * g + 2] - mean2) * rstd2, gv.z, bv.z);
+          const float y3 = fmaf((o[mt][4 * g + 3] - mean2) * rstd2, gv.w, bv.w);
+          d[2 * gg2 + 0] = pack_bf16(y0, y1);
+          d[2 * gg2 + 1] = pack_bf16(y2, y3);
+        }
+        uint4 st = {d[0], d[1], d[2], d[3]};
+        row16_to_corder(st);   // involution: C-order -> natural 16 bytes at [16u + 8h]
+        if (jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
+      }
+    }
+    // ---- end of the query row: merge the two lane halves' softmax states, write the x_out input
+#pragma unroll
+    for (int cb = 0; cb < C::NCB; ++cb) {
+      const float m_ = sS[(cb * 3 + 0) * 64], l_ = sS[(cb * 3 + 1) * 64], a_ = sS[(cb * 3 + 2) * 64];
+      const float mo = __shfl_xor(m_, 32), lo = __shfl_xor(l_, 32), ao = __shfl_xor(a_, 32);
+      const float M = fmaxf(m_, mo);
+      const float s0 = __expf(m_ - M), s1 = __expf(mo - M);
+      const float l = l_ * s0 + lo * s1, av = a_ * s0 + ao * s1;
+      if (h == 0) {
+        const int c = 32 * cb + r;
+        a.newX_in[(size_t)row * DX + c] = fmaf(a.yx2p1[(size_t)b * DX + c], av / l, a.yx1[(size_t)b * DX + c]);
+      }
+    }
+  }
+}
+
+// K,V (fp32, natural (B,n,DX), already masked) -> bf16 fragment layout
+//   [b][jt][cb][kv][half2][lane][8]: element e of (half2,lane=(r,h)) is row 32jt + crow(8*half2+e, h), channel 32cb + r
+__global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, int B, int n, int DX) {
+  const int NT = (n + 31) / 32, NCB = DX / 32;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t tot = (size_t)B * NT * NCB * 4 * 64;
+  if (t >= tot) return;
+  const int lane = t & 63; const int half2 = (t >> 6) & 1; const int kv = (t >> 7) & 1;
+  size_t rest = t >> 8;
+  const int cb = rest % NCB; rest /= NCB;
+  const int jt = rest % NT; const int b = rest / NT;
+  const int r = lane & 31, h = lane >> 5;
+  const float* src = kv ? V : K;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int j = 32 * jt + crow(8 * half2 + e, h);
+    v[e] = j < n ? src[((size_t)b * n + j) * ldkv + 32 * cb + r] : 0.f;
+  }
+  uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  out[t] = o;
+}
+
+// per-graph pooled statistics of the bf16 edge tensor (Etoy, neuralnet/layers.py:31-47): partial sums per chunk
+//   out[b][chunk][4][DE] = (sum, sum of squares, min, max) over the chunk's pairs (padding and diagonal included)
+template <int DE>
+__global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, int n, int nchunk) {
+  constexpr int G = DE / 8;            // 16-byte groups per row
+  constexpr int RL = 256 / G;          // rows handled concurrently
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const size_t N = (size_t)n * n;
+  const size_t per = (N + nchunk - 1) / nchunk;
+  const size_t p0 = ch * per, p1 = min(N, p0 + per);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  float s[8], ss[8], mn[8], mx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; mn[e] = INFINITY; mx[e] = -INFINITY; }
+  const bf16_t* base = E + (size_t)b * N * DE;
+  for (size_t p = p0 + rl; p < p1; p += RL) {
+    const uint4 u = *reinterpret_cast<const uint4*>(base + p * DE + 8 * g);
+    const unsigned d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
+      s[e] += v; ss[e] = fmaf(v, v, ss[e]); mn[e] = fminf(mn[e], v); mx[e] = fmaxf(mx[e], v);
+    }
+  }
+  __shared__ float red[4][256][8 + 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; red[2][threadIdx.x][e] = mn[e]; red[3][threadIdx.x][e] = mx[e]; }
+  __syncthreads();
+  if (threadIdx.x < DE) {
+    const int c = threadIdx.x, gg = c / 8, e = c % 8;
+    float a0 = 0.f, a1 = 0.f, a2 = INFINITY, a3 = -INFINITY;
+    for (int k = 0; k < RL; ++k) {
+      const int t = k * G + gg;
+      a0 += red[0][t][e]; a1 += red[1][t][e]; a2 = fminf(a2, red[2][t][e]); a3 = fmaxf(a3, red[3][t][e]);
+    }
+    float* o = out + ((size_t)(b * nchunk + ch) * 4) * DE;
+    o[c] = a0; o[DE + c] = a1; o[2 * DE + c] = a2; o[3 * DE + c] = a3;
+  }
+}
+
+// ===================================================================================================
+template <int DE, int DX, int DFF>
+static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+  using C = EdgeCfg<DE, DX, DFF>;
+  constexpr int NT_ = 256;
+  auto kern = k_edge_layer<DE, DX, DFF, NT_>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * C::STATE_BYTES_PER_WAVE));
+    if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
+    attr_set = true;
+  }
+  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * C::STATE_BYTES_PER_WAVE, s>>>(a);
+  return DA_OK;
+}
+
+extern "C" {
+
+// size in bytes of the packed per-layer weight blob the edge kernel expects (layout: EdgeCfg / diffalign_amd/pack.py)
+long long da_edge_blob_bytes(int de, int dx, int dff) {
+  if (de == 64 && dx == 256 && dff == 128) return (long long)EdgeCfg<64, 256, 128>::BLOB_BYTES;
+  if (de == 32 && dx == 64 && dff == 64) return (long long)EdgeCfg<32, 64, 64>::BLOB_BYTES;
+  return -1;
+}
+long long da_kv_frag_bytes(int B, int n, int dx) { return (long long)B * ((n + 31) / 32) * (dx / 32) * 4 * 64 * 16; }
+
+int da_kv_pack(const float* K, const float* V, int ldkv, void* out, int B, int n, int dx, void* stream) {
+  DA_CHECK_ARG(dx % 32 == 0 && ldkv >= dx, "da_kv_pack: dx must be a multiple of 32");
+  if (B == 0 || n == 0) return DA_OK;
+  size_t tot = (size_t)B * ((n + 31) / 32) * (dx / 32) * 4 * 64;
+  k_kv_pack<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(K, V, ldkv, (uint4*)out, B, n, dx);
+  DA_CHECK_LAUNCH("da_kv_pack");
+  return DA_OK;
+}
+
+int da_edge_stats(const void* E_bf16, float* partials, int B, int n, int de, int nchunk, void* stream) {
+  DA_CHECK_ARG(nchunk >= 1, "da_edge_stats: nchunk < 1");
+  if (B == 0 || n == 0) return DA_OK;
+  dim3 grid(nchunk, B);
+  if (de == 64) k_e_stats<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
+  else if (de == 32) k_e_stats<32><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
+  else { da_set_error("da_edge_stats: de=%d not built (32, 64)", de); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_stats");
+  return DA_OK;
+}
+
+// Fused edge side of one XEyTransformerLayer (see file header).  All pointers device; E bf16.
+int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                  const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
+  DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
+  if (B == 0 || n == 0) return DA_OK;
+  EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
+                  newX_in, (const uint4*)blob, qscale, B, n};
+  const int rows = B * n;
+  int grid = 256;                                   // one persistent workgroup per CU
+  int need = ((rows + 3) / 4 + 7) / 8 * 8;
+  if (need < grid) grid = need < 8 ? 8 : need;
+  int rc;
+  if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
+  else if (de == 32 && dx == 64 && dff == 64) rc = launch_edge<32, 64, 64>(a, grid, (hipStream_t)stream);
+  else { da_set_error("da_edge_layer: dims (de=%d, dx=%d, dffE=%d) not built; built: (64,256,128), (32,64,64)", de, dx, dff); return DA_ERR_UNSUPPORTED; }
+  if (rc) return rc;
+  DA_CHECK_LAUNCH("da_edge_layer");
+  return DA_OK;
+}
+
+}  // extern "C"

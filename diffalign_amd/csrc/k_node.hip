@@ -1,0 +1,355 @@
+// Node-side (X) and global (y) kernels of the denoiser.  The X path is a handful of small dense contractions
+// (B*n rows x 256) -> MFMA bf16 with fp32 accumulate; the y path is per-graph vector work -> fp32 VALU.
+#include "mfma_util.h"
+#include <climits>
+
+// ---------------------------------------------------------------------------------------------------
+// out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask).  A fp32 (lda), W bf16 row-major [Npad][Kpad] (zero padded to
+// multiples of 32 / 16 by diffalign_amd/pack.py), out fp32 (ldc).  One wave = 32 rows x (32*NTILE) columns; fragments
+// are loaded straight from global/L2 (the operands are small and hot), no LDS.
+template <int NTILE, bool RELU>
+__global__ void __launch_bounds__(256) k_linear(const float* __restrict__ A, int lda, const bf16_t* __restrict__ W, int Kpad,
+                                                const float* __restrict__ bias, const uint8_t* __restrict__ rowmask,
+                                                float* __restrict__ out, int ldc, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 32 * NTILE;
+  if (m0 >= M) return;
+  const int arow = min(m0 + r, M - 1);
+  const float* ap = A + (size_t)arow * lda;
+  f32x16 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = splat16(0.f);
+  const bool vec_ok = ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+  for (int k0 = 0; k0 < Kpad; k0 += 16) {
+    const int kb = k0 + 8 * h;
+    float av[8];
+    if (vec_ok && kb + 8 <= K) {
+      const float4 x0 = *reinterpret_cast<const float4*>(ap + kb), x1 = *reinterpret_cast<const float4*>(ap + kb + 4);
+      av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
+    }
+    uint4 au = {pack_bf16(av[0], av[1]), pack_bf16(av[2], av[3]), pack_bf16(av[4], av[5]), pack_bf16(av[6], av[7])};
+    const bf16x8 af = frag_from_u4(au);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const uint4 wu = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + 32 * t + r) * Kpad + kb);
+      acc[t] = mfma32(af, frag_from_u4(wu), acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int col = n0 + 32 * t + r;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + crow(i, h);
+      if (row >= M) continue;
+      float v = acc[t][i] + bv;
+      if (RELU) v = fmaxf(v, 0.f);
+      if (rowmask) v = rowmask[row] ? v : 0.f;
+      out[(size_t)row * ldc + col] = v;
+    }
+  }
+}
+
+// out = LayerNorm(a + b) * g + beta, one wave per row (D <= 1024)
+__global__ void __launch_bounds__(256) k_add_layernorm(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ g, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[16];
+  float s = 0.f;
+  const int per = (D + 63) / 64;
+#pragma unroll 4
+  for (int k = 0; k < per; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < D ? a[(size_t)row * D + c] + (b ? b[(size_t)row * D + c] : 0.f) : 0.f;
+    s += v[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / D;
+  float q = 0.f;
+  for (int k = 0; k < per; ++k) { const int c = lane + 64 * k; const float d = c < D ? v[k] - mean : 0.f; q = fmaf(d, d, q); }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / D + 1e-5f);
+  for (int k = 0; k < per; ++k) {
+    const int c = lane + 64 * k;
+    if (c < D) out[(size_t)row * D + c] = fmaf((v[k] - mean) * rstd, g[c], beta[c]);
+  }
+}
+
+// after mlp_in_X: mask rows, encode_no_element on the hidden features, add positional encodings
+// (neuralnet/transformer_model_with_y.py:661,666)
+__global__ void k_x_in_finish(float* X, const uint8_t* nm, const float* pos, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float m = nm[row] ? 1.f : 0.f;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += X[(size_t)row * D + c] * m;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  for (int c = lane; c < D; c += 64) {
+    float v = X[(size_t)row * D + c] * m;
+    if (c == 0 && s == 0.f) v = 1.f;
+    if (pos) v += pos[(size_t)row * D + c];
+    X[(size_t)row * D + c] = v;
+  }
+}
+
+// X_o = mlp_out_X(X_h) + X_in[..., :Kx]  (+ s1 * X_in[src]) -- transformer_model_with_y.py:676,699-701
+__global__ void k_x_out_finish(const float* lin, int ldl, const float* Xin, int dxin, const int* src, const float* s1p,
+                               float* out, int B, int n, int Kx) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * n * Kx) return;
+  const int c = t % Kx; const size_t row = t / Kx; const int b = row / n;
+  float v = lin[row * ldl + c] + Xin[row * dxin + c];
+  if (src) { const int sidx = src[row]; if (sidx >= 0) v += s1p[0] * Xin[((size_t)b * n + sidx) * dxin + c]; }
+  out[t] = v;
+}
+
+// alignment gather index (semantics of transformer_model_with_y.py:506-555, alignment_type='correct'):
+// src[b,r] = product node with the same atom-map number as reactant-side node r, else -1.  One block per graph.
+__global__ void k_align_index(const int64_t* am, const int64_t* mol, int* src, int n) {
+  const int b = blockIdx.x;
+  __shared__ int s_prod;
+  if (threadIdx.x == 0) s_prod = INT_MIN;
+  __syncthreads();
+  int mx = INT_MIN;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = max(mx, (int)mol[(size_t)b * n + i]);
+  atomicMax(&s_prod, mx);
+  __syncthreads();
+  const long long prod = s_prod;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int res = -1;
+    const long long a = am[(size_t)b * n + i];
+    if (a > 0 && mol[(size_t)b * n + i] != prod) {
+      for (int j = 0; j < n; ++j)
+        if (mol[(size_t)b * n + j] == prod && am[(size_t)b * n + j] == a) { res = j; break; }
+    }
+    src[(size_t)b * n + i] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y path.  One workgroup (256 threads) per graph; vectors live in LDS.
+// wave-cooperative mat-vec: out[o] = act(b[o] + sum_k W[o*ldw + k] * v[k])
+__device__ __forceinline__ void block_matvec(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                             const float* v, float* out, int O, int K, bool relu, float addc = 0.f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int o = wave; o < O; o += nw) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(W[(size_t)o * ldw + k], v[k], s);
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) { s += (bias ? bias[o] : 0.f) + addc; out[o] = relu ? fmaxf(s, 0.f) : s; }
+  }
+}
+__device__ __forceinline__ void block_layernorm(const float* x, const float* g, const float* b, float* out, int D) {
+  // D <= 256; every thread computes the statistics redundantly from LDS
+  float s = 0.f;
+  for (int k = 0; k < D; ++k) s += x[k];
+  const float mean = s / D;
+  float q = 0.f;
+  for (int k = 0; k < D; ++k) { const float d = x[k] - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(q / D + 1e-5f);
+  __syncthreads();
+  for (int k = threadIdx.x; k < D; k += blockDim.x) out[k] = fmaf((x[k] - mean) * rstd, g[k], b[k]);
+  __syncthreads();
+}
+
+struct YInArgs { const float* y; const float* W0; const float* b0; const float* W1; const float* b1; float* out; int din, dh, dy; };
+// y_h = relu(W1 relu(W0 y + b0) + b1)   (mlp_in_y, transformer_model_with_y.py:590-591)
+__global__ void __launch_bounds__(256) k_y_in(YInArgs a) {
+  extern __shared__ float sm[];
+  float* v = sm; float* hbuf = sm + a.din;
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < a.din; k += blockDim.x) v[k] = a.y[(size_t)b * a.din + k];
+  __syncthreads();
+  block_matvec(a.W0, a.din, a.b0, v, hbuf, a.dh, a.din, true);
+  __syncthreads();
+  block_matvec(a.W1, a.dh, a.b1, hbuf, a.out + (size_t)b * a.dy, a.dy, a.dh, true);
+}
+
+struct YFilmArgs {
+  const float* y;                                     // (B,dy)
+  const float *We_add, *be_add, *We_mul, *be_mul;     // y_e_add / y_e_mul  (dx,dy)
+  const float *Wx_add, *bx_add, *Wx_mul, *bx_mul;     // y_x_add / y_x_mul  (dx,dy)
+  const float *Wout, *bout;                           // e_out (de,dx)
+  float *ye2p1, *ebias, *yx1, *yx2p1;
+  int dy, dx, de;
+};
+// FiLM vectors of one layer (layers.py:245-247,268-270); the additive edge FiLM is folded through e_out:
+//   e_out(ye1 + (ye2+1)*Y) = e_out.W((ye2+1)*Y) + [e_out.b + e_out.W ye1]
+__global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
+  extern __shared__ float sm[];
+  float* v = sm; float* ye1 = sm + a.dy;
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v[k] = a.y[(size_t)b * a.dy + k];
+  __syncthreads();
+  block_matvec(a.We_add, a.dy, a.be_add, v, ye1, a.dx, a.dy, false);
+  block_matvec(a.We_mul, a.dy, a.be_mul, v, a.ye2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
+  block_matvec(a.Wx_add, a.dy, a.bx_add, v, a.yx1 + (size_t)b * a.dx, a.dx, a.dy, false);
+  block_matvec(a.Wx_mul, a.dy, a.bx_mul, v, a.yx2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
+  __syncthreads();
+  block_matvec(a.Wout, a.dx, a.bout, ye1, a.ebias + (size_t)b * a.de, a.de, a.dx, false);
+}
+
+struct YUpdArgs {
+  const float* y; const float* X; const uint8_t* nm; const float* estats;   // estats: (B,nchunk,4,de) partials
+  const float *Wxy, *bxy, *Wey, *bey;                 // x_y.lin (dy,4dx), e_y.lin (dy,4de)
+  const float *Wo0, *bo0, *Wo2, *bo2;                 // y_out.0 / .2
+  const float *n1g, *n1b, *W1, *b1, *W2, *b2, *n2g, *n2b;   // norm_y1, lin_y1 (dff,dy), lin_y2 (dy,dff), norm_y2
+  float* out;
+  int n, dx, de, dy, dff, nchunk;
+};
+// new_y = y_out(y + Xtoy(X) + Etoy(E)); y = LN(y+new_y); y = LN(y + lin_y2(relu(lin_y1(y))))
+// (layers.py:15-47,277-281,346-359).  Statistics run over ALL n nodes / n^2 pairs (padding included), std unbiased.
+__global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
+  extern __shared__ float sm[];
+  float* sx = sm;                       // 4*dx
+  float* se = sx + 4 * a.dx;            // 4*de
+  float* v0 = se + 4 * a.de;            // dy
+  float* v1 = v0 + a.dy;                // dy
+  float* v2 = v1 + a.dy;                // dy
+  float* hb = v2 + a.dy;                // dff
+  const int b = blockIdx.x, n = a.n;
+  for (int c = threadIdx.x; c < a.dx; c += blockDim.x) {
+    const float* xp = a.X + (size_t)b * n * a.dx + c;
+    double s = 0.0; float mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < n; ++i) { const float x = xp[(size_t)i * a.dx]; s += x; mn = fminf(mn, x); mx = fmaxf(mx, x); }
+    const double mean = s / n;
+    double q = 0.0;
+    for (int i = 0; i < n; ++i) { const double d = xp[(size_t)i * a.dx] - mean; q += d * d; }
+    sx[c] = (float)mean; sx[a.dx + c] = mn; sx[2 * a.dx + c] = mx; sx[3 * a.dx + c] = n > 1 ? (float)sqrt(q / (n - 1)) : 0.f;
+  }
+  for (int c = threadIdx.x; c < a.de; c += blockDim.x) {
+    double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < a.nchunk; ++k) {
+      const float* p = a.estats + ((size_t)(b * a.nchunk + k) * 4) * a.de;
+      s += p[c]; q += p[a.de + c]; mn = fminf(mn, p[2 * a.de + c]); mx = fmaxf(mx, p[3 * a.de + c]);
+    }
+    const double N = (double)n * n, mean = s / N;
+    double var = N > 1 ? (q - N * mean * mean) / (N - 1) : 0.0;
+    if (var < 0) var = 0;
+    se[c] = (float)mean; se[a.de + c] = mn; se[2 * a.de + c] = mx; se[3 * a.de + c] = (float)sqrt(var);
+  }
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v0[k] = a.y[(size_t)b * a.dy + k];
+  __syncthreads();
+  block_matvec(a.Wxy, 4 * a.dx, a.bxy, sx, v1, a.dy, 4 * a.dx, false);
+  block_matvec(a.Wey, 4 * a.de, a.bey, se, v2, a.dy, 4 * a.de, false);
+  __syncthreads();
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] = v0[k] + v1[k] + v2[k];
+  __syncthreads();
+  block_matvec(a.Wo0, a.dy, a.bo0, v1, v2, a.dy, a.dy, true);
+  __syncthreads();
+  block_matvec(a.Wo2, a.dy, a.bo2, v2, v1, a.dy, a.dy, false);
+  __syncthreads();
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
+  __syncthreads();
+  block_layernorm(v1, a.n1g, a.n1b, v0, a.dy);       // v0 = y after norm_y1
+  block_matvec(a.W1, a.dy, a.b1, v0, hb, a.dff, a.dy, true);
+  __syncthreads();
+  block_matvec(a.W2, a.dff, a.b2, hb, v1, a.dy, a.dff, false);
+  __syncthreads();
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
+  __syncthreads();
+  block_layernorm(v1, a.n2g, a.n2b, a.out + (size_t)b * a.dy, a.dy);
+}
+
+// ===================================================================================================
+extern "C" {
+
+int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float* bias, const uint8_t* rowmask, float* out,
+              int ldc, int M, int N, int K, int relu, void* stream) {
+  DA_CHECK_ARG(Kpad % 16 == 0 && Kpad >= K, "da_linear: Kpad must be a multiple of 16 and >= K");
+  if (M == 0 || N == 0) return DA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* W = (const bf16_t*)W_bf16;
+  const int Npad = (N + 31) / 32 * 32;
+  const int gm = (M + 127) / 128;
+  if (Npad % 128 == 0) {
+    dim3 grid(gm, Npad / 128);
+    if (relu) k_linear<4, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+    else k_linear<4, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+  } else if (Npad % 64 == 0) {
+    dim3 grid(gm, Npad / 64);
+    if (relu) k_linear<2, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+    else k_linear<2, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+  } else {
+    dim3 grid(gm, Npad / 32);
+    if (relu) k_linear<1, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+    else k_linear<1, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+  }
+  DA_CHECK_LAUNCH("da_linear");
+  return DA_OK;
+}
+
+int da_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* out, int rows, int D,
+                     void* stream) {
+  DA_CHECK_ARG(D >= 1 && D <= 1024, "da_add_layernorm: D out of range");
+  if (rows == 0) return DA_OK;
+  k_add_layernorm<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(a, b, gamma, beta, out, rows, D);
+  DA_CHECK_LAUNCH("da_add_layernorm");
+  return DA_OK;
+}
+
+int da_x_in_finish(float* X, const uint8_t* node_mask, const float* pos, int rows, int D, void* stream) {
+  if (rows == 0) return DA_OK;
+  k_x_in_finish<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(X, node_mask, pos, rows, D);
+  DA_CHECK_LAUNCH("da_x_in_finish");
+  return DA_OK;
+}
+
+int da_x_out_finish(const float* lin, int ldl, const float* X_in, int dx_in, const int* src, const float* skip_scale,
+                    float* out, int B, int n, int kx, void* stream) {
+  if (B == 0 || n == 0) return DA_OK;
+  size_t tot = (size_t)B * n * kx;
+  k_x_out_finish<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(lin, ldl, X_in, dx_in, src, skip_scale, out, B, n, kx);
+  DA_CHECK_LAUNCH("da_x_out_finish");
+  return DA_OK;
+}
+
+int da_align_index(const int64_t* atom_map_numbers, const int64_t* mol_assignments, int* src, int B, int n, void* stream) {
+  if (B == 0 || n == 0) return DA_OK;
+  k_align_index<<<B, 256, 0, (hipStream_t)stream>>>(atom_map_numbers, mol_assignments, src, n);
+  DA_CHECK_LAUNCH("da_align_index");
+  return DA_OK;
+}
+
+int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, float* out, int B, int din,
+            int dh, int dy, void* stream) {
+  if (B == 0) return DA_OK;
+  YInArgs a{y, W0, b0, W1, b1, out, din, dh, dy};
+  k_y_in<<<B, 256, (din + dh) * sizeof(float), (hipStream_t)stream>>>(a);
+  DA_CHECK_LAUNCH("da_y_in");
+  return DA_OK;
+}
+
+int da_y_film(const float* y, const float* const* w /* 10 pointers, YFilmArgs order */, float* ye2p1, float* ebias,
+              float* yx1, float* yx2p1, int B, int dy, int dx, int de, void* stream) {
+  if (B == 0) return DA_OK;
+  YFilmArgs a{y, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], ye2p1, ebias, yx1, yx2p1, dy, dx, de};
+  k_y_film<<<B, 256, (dy + dx) * sizeof(float), (hipStream_t)stream>>>(a);
+  DA_CHECK_LAUNCH("da_y_film");
+  return DA_OK;
+}
+
+int da_y_update(const float* y, const float* X, const uint8_t* node_mask, const float* estats,
+                const float* const* w /* 16 pointers, YUpdArgs order */, float* out, int B, int n, int dx, int de, int dy,
+                int dff, int nchunk, void* stream) {
+  if (B == 0) return DA_OK;
+  YUpdArgs a{y, X, node_mask, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+             w[14], w[15], out, n, dx, de, dy, dff, nchunk};
+  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff) * sizeof(float);
+  k_y_update<<<B, 256, sh, (hipStream_t)stream>>>(a);
+  DA_CHECK_LAUNCH("da_y_update");
+  return DA_OK;
+}
+
+}  // extern "C"

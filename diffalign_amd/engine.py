@@ -1,0 +1,187 @@
+"""Host-side driver of the denoiser forward: packs the nn.Module's parameters once (re-packs when they change) and
+issues the C-ABI calls of include/diffalign_hip.h in order.  PyTorch only owns memory and the stream."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from . import pack
+
+N_STAT_CHUNKS = 32
+
+
+def _i(v):
+    return C.c_int(int(v))
+
+
+class _PtrArray:
+    """ctypes array of device pointers (host memory) + the tensors it references kept alive."""
+
+    def __init__(self, tensors):
+        self.keep = list(tensors)
+        self.arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class PackedModel:
+    def __init__(self, sd: Dict[str, torch.Tensor], device, n_layers: int, n_head: int, prefix: str = ''):
+        g = lambda k: sd[prefix + k]
+        dev = device
+        f32 = lambda t: t.detach().float().contiguous().to(dev)
+        bw = lambda k: pack.bf16_weight(g(k)).to(dev)
+        self.n_layers, self.n_head = n_layers, n_head
+        self.dx = g('mlp_in_X.2.weight').shape[0]
+        self.de = g('mlp_in_E.2.weight').shape[0]
+        self.dy = g('mlp_in_y.2.weight').shape[0]
+        self.hx = g('mlp_in_X.0.weight').shape[0]
+        self.he = g('mlp_in_E.0.weight').shape[0]
+        self.hy = g('mlp_in_y.0.weight').shape[0]
+        self.dffx = g('tf_layers.0.linX1.weight').shape[0]
+        self.dffe = g('tf_layers.0.linE1.weight').shape[0]
+        self.dffy = g('tf_layers.0.lin_y1.weight').shape[0]
+        self.kx = g('mlp_out_X.2.weight').shape[0]
+        self.ke = g('mlp_out_E.2.weight').shape[0]
+        self.dx_in = g('mlp_in_X.0.weight').shape[1]
+        self.de_in = g('mlp_in_E.0.weight').shape[1]
+        self.dy_in = g('mlp_in_y.0.weight').shape[1]
+        lib = L.lib()
+        lib.da_edge_blob_bytes.restype = C.c_longlong
+        if lib.da_edge_blob_bytes(_i(self.de), _i(self.dx), _i(self.dffe)) < 0:
+            raise L.DiffAlignHipError(f'hidden dims (de={self.de}, dx={self.dx}, dim_ffE={self.dffe}) are not built into '
+                                      'libdiffalign_hip.so; built: (64,256,128) and (32,64,64)')
+        self.in_X = [bw('mlp_in_X.0.weight'), f32(g('mlp_in_X.0.bias')), bw('mlp_in_X.2.weight'), f32(g('mlp_in_X.2.bias'))]
+        self.in_y = [f32(g('mlp_in_y.0.weight')), f32(g('mlp_in_y.0.bias')), f32(g('mlp_in_y.2.weight')), f32(g('mlp_in_y.2.bias'))]
+        self.in_E = pack.edge_in_blob(sd, prefix).to(dev)
+        self.out_X = [bw('mlp_out_X.0.weight'), f32(g('mlp_out_X.0.bias')), bw('mlp_out_X.2.weight'), f32(g('mlp_out_X.2.bias'))]
+        self.out_E = pack.edge_out_blob(sd, prefix).to(dev)
+        self.skip = None
+        if prefix + 'skip_scaling' in sd:
+            self.skip = (f32(g('skip_scaling')), f32(g('skip_scaling_2')))
+        self.layers = []
+        for l in range(n_layers):
+            p = f'tf_layers.{l}'
+            a = p + '.self_attn'
+            Wqkv = torch.cat([g(a + '.q.weight'), g(a + '.k.weight'), g(a + '.v.weight')], 0)
+            bqkv = torch.cat([g(a + '.q.bias'), g(a + '.k.bias'), g(a + '.v.bias')], 0)
+            film = [f32(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
+                                            '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias',
+                                            '.e_out.weight', '.e_out.bias')]
+            yup = [f32(g(k)) for k in (a + '.x_y.lin.weight', a + '.x_y.lin.bias', a + '.e_y.lin.weight', a + '.e_y.lin.bias',
+                                       a + '.y_out.0.weight', a + '.y_out.0.bias', a + '.y_out.2.weight', a + '.y_out.2.bias',
+                                       p + '.norm_y1.weight', p + '.norm_y1.bias', p + '.lin_y1.weight', p + '.lin_y1.bias',
+                                       p + '.lin_y2.weight', p + '.lin_y2.bias', p + '.norm_y2.weight', p + '.norm_y2.bias')]
+            self.layers.append(dict(
+                blob=pack.edge_layer_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev),
+                Wqkv=pack.bf16_weight(Wqkv).to(dev), bqkv=f32(bqkv),
+                Wxo=bw(a + '.x_out.weight'), bxo=f32(g(a + '.x_out.bias')),
+                W1=bw(p + '.linX1.weight'), b1=f32(g(p + '.linX1.bias')), W2=bw(p + '.linX2.weight'), b2=f32(g(p + '.linX2.bias')),
+                n1=(f32(g(p + '.normX1.weight')), f32(g(p + '.normX1.bias'))),
+                n2=(f32(g(p + '.normX2.weight')), f32(g(p + '.normX2.bias'))),
+                film=_PtrArray(film), yup=_PtrArray(yup)))
+
+
+def _linear(A, lda, W, bias, rowmask, out, ldc, M, N, K, relu):
+    L.check(L.lib().da_linear(L.ptr(A) if isinstance(A, torch.Tensor) else A, _i(lda), L.ptr(W), _i(W.shape[1]), L.ptr(bias),
+                              L.ptr(rowmask), L.ptr(out) if isinstance(out, torch.Tensor) else out, _i(ldc), _i(M), _i(N),
+                              _i(K), _i(1 if relu else 0), L.stream()), 'da_linear')
+
+
+def edge_stats(E_bf16, B, n, de):
+    st = torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
+    L.check(L.lib().da_edge_stats(L.ptr(E_bf16), L.ptr(st), _i(B), _i(n), _i(de), _i(N_STAT_CHUNKS), L.stream()), 'da_edge_stats')
+    return st
+
+
+def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
+    """One XEyTransformerLayer (neuralnet/layers.py:330-361).  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32."""
+    dev = X.device
+    dx, de, dy = pm.dx, pm.de, pm.dy
+    R = B * n
+    lib = L.lib()
+    S = L.stream()
+    ye2p1 = torch.empty(B, dx, device=dev); ebias = torch.empty(B, de, device=dev)
+    yx1 = torch.empty(B, dx, device=dev); yx2p1 = torch.empty(B, dx, device=dev)
+    L.check(lib.da_y_film(L.ptr(y), lw['film'].arr, L.ptr(ye2p1), L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), _i(B), _i(dy), _i(dx),
+                          _i(de), S), 'da_y_film')
+    qkv = torch.empty(R, 3 * dx, device=dev)
+    _linear(X, dx, lw['Wqkv'], lw['bqkv'], nm_u8, qkv, 3 * dx, R, 3 * dx, dx, False)
+    lib.da_kv_frag_bytes.restype = C.c_longlong
+    kvf = torch.empty(lib.da_kv_frag_bytes(_i(B), _i(n), _i(dx)), dtype=torch.uint8, device=dev)
+    fsz = 4
+    L.check(lib.da_kv_pack(C.c_void_p(qkv.data_ptr() + dx * fsz), C.c_void_p(qkv.data_ptr() + 2 * dx * fsz), _i(3 * dx),
+                           L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
+    E_out = torch.empty_like(E_bf16)
+    newX_in = torch.empty(R, dx, device=dev)
+    L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(qkv), _i(3 * dx), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
+                              L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
+                              C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe), S),
+            'da_edge_layer')
+    newX = torch.empty(R, dx, device=dev)
+    _linear(newX_in, dx, lw['Wxo'], lw['bxo'], nm_u8, newX, dx, R, dx, dx, False)
+    X1 = torch.empty(R, dx, device=dev)
+    L.check(lib.da_add_layernorm(L.ptr(X), L.ptr(newX), L.ptr(lw['n1'][0]), L.ptr(lw['n1'][1]), L.ptr(X1), _i(R), _i(dx), S),
+            'da_add_layernorm')
+    hbuf = torch.empty(R, pm.dffx, device=dev)
+    _linear(X1, dx, lw['W1'], lw['b1'], None, hbuf, pm.dffx, R, pm.dffx, dx, True)
+    ff = newX
+    _linear(hbuf, pm.dffx, lw['W2'], lw['b2'], None, ff, dx, R, dx, pm.dffx, False)
+    X2 = torch.empty(B, n, dx, device=dev)
+    L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
+            'da_add_layernorm')
+    y2 = torch.empty(B, dy, device=dev)
+    L.check(lib.da_y_update(L.ptr(y), L.ptr(X), L.ptr(nm_u8), L.ptr(estats), lw['yup'].arr, L.ptr(y2), _i(B), _i(n), _i(dx),
+                            _i(de), _i(dy), _i(pm.dffy), _i(N_STAT_CHUNKS), S), 'da_y_update')
+    return X2, E_out, y2
+
+
+def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
+                  use_skip=False):
+    """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713)."""
+    dev = X.device
+    B, n = X.shape[:2]
+    R = B * n
+    lib = L.lib()
+    S = L.stream()
+    X = X.contiguous().float(); E = E.contiguous().float(); y = y.contiguous().float()
+    assert X.shape[-1] == pm.dx_in and E.shape[-1] == pm.de_in and y.shape[-1] == pm.dy_in, 'input feature widths'
+    nm = L.as_u8(node_mask)
+    # ---- input stage
+    h0 = torch.empty(R, pm.hx, device=dev)
+    _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
+    Xh = torch.empty(B, n, pm.dx, device=dev)
+    _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
+    pos = pos_encodings.contiguous().float() if pos_encodings is not None else None
+    L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), S), 'da_x_in_finish')
+    Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
+    L.check(lib.da_edge_in(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), _i(B), _i(n), _i(pm.de), _i(pm.he), S),
+            'da_edge_in')
+    yh = torch.empty(B, pm.dy, device=dev)
+    L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
+                        _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
+    # ---- layers
+    for lw in pm.layers:
+        st = edge_stats(Eh, B, n, pm.de)
+        Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
+    # ---- output stage
+    h1 = torch.empty(R, pm.hx, device=dev)
+    _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)
+    lin = torch.empty(R, pm.kx, device=dev)
+    _linear(h1, pm.hx, pm.out_X[2], pm.out_X[3], None, lin, pm.kx, R, pm.kx, pm.hx, False)
+    src = None
+    s1 = s2 = None
+    if use_skip:
+        assert pm.skip is not None and atom_map_numbers is not None and mol_assignments is not None
+        src = torch.empty(B, n, dtype=torch.int32, device=dev)
+        L.check(lib.da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
+                                   L.ptr(src), _i(B), _i(n), S), 'da_align_index')
+        s1, s2 = pm.skip
+    Xo = torch.empty(B, n, pm.kx, device=dev)
+    L.check(lib.da_x_out_finish(L.ptr(lin), _i(pm.kx), L.ptr(X), _i(pm.dx_in), L.ptr(src), L.ptr(s1), L.ptr(Xo), _i(B), _i(n),
+                                _i(pm.kx), S), 'da_x_out_finish')
+    Eo = torch.empty(B, n, n, pm.ke, device=dev)
+    L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B),
+                            _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out')
+    return Xo, Eo, yh

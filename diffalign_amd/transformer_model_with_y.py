@@ -1,0 +1,93 @@
+"""Denoiser modules with the reference's nn.Module contract (diffalign/neuralnet/transformer_model_with_y.py:
+GraphTransformerWithY :33-112, GraphTransformerWithYAtomMapPosEmb :557-714): same constructor arguments, same
+state-dict keys/shapes, same forward signature and 4-tuple result.  forward() runs in libdiffalign_hip.so
+(bf16 MFMA, fp32 accumulate) -- no eager fallback."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine
+from .layers import XEyTransformerLayer
+
+
+class _DenoiserBase(nn.Module):
+    def _build(self, n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in, act_fn_out, improved,
+               dropout):
+        self.n_layers = n_layers
+        self.n_head = hidden_dims['n_head']
+        self.out_dim_X, self.out_dim_E, self.out_dim_y = output_dims['X'], output_dims['E'], output_dims['y']
+        if not isinstance(act_fn_in, nn.ReLU) or not isinstance(act_fn_out, nn.ReLU):
+            raise NotImplementedError('only ReLU activations are built (the reference never passes anything else)')
+        mk = lambda a, b, c, last_act: nn.Sequential(*([nn.Linear(a, b), nn.ReLU(), nn.Linear(b, c)] + ([nn.ReLU()] if last_act else [])))
+        self.mlp_in_X = mk(input_dims['X'], hidden_mlp_dims['X'], hidden_dims['dx'], True)
+        self.mlp_in_E = mk(input_dims['E'], hidden_mlp_dims['E'], hidden_dims['de'], True)
+        self.mlp_in_y = mk(input_dims['y'], hidden_mlp_dims['y'], hidden_dims['dy'], True)
+        self.tf_layers = nn.ModuleList([XEyTransformerLayer(dx=hidden_dims['dx'], de=hidden_dims['de'], dy=hidden_dims['dy'],
+                                                            n_head=hidden_dims['n_head'], dim_ffX=hidden_dims['dim_ffX'],
+                                                            dim_ffE=hidden_dims['dim_ffE'], improved=improved, dropout=dropout)
+                                        for _ in range(n_layers)])
+        self.mlp_out_X = mk(hidden_dims['dx'], hidden_mlp_dims['X'], output_dims['X'], False)
+        self.mlp_out_E = mk(hidden_dims['de'], hidden_mlp_dims['E'], output_dims['E'], False)
+        self.mlp_out_y = mk(hidden_dims['dy'], hidden_mlp_dims['y'], output_dims['y'], False)   # unused by forward, kept for checkpoints
+        self._packed = None
+        self._packed_key = None
+
+    def _pack(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or self._packed_key != key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._packed = engine.PackedModel(sd, device, self.n_layers, self.n_head)
+            self._packed_key = key
+        return self._packed
+
+    def _check(self, X):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError('diffalign_amd: the HIP denoiser is forward-only in this round (training/backward '
+                                      'is SURVEY §8 config 4, not built yet); call under torch.no_grad() / .eval()')
+        if not X.is_cuda:
+            raise L.DiffAlignHipError('denoiser inputs must be on a HIP device (no CPU fallback)')
+
+
+class GraphTransformerWithY(_DenoiserBase):
+    def __init__(self, n_layers: int, input_dims: dict, hidden_mlp_dims: dict, hidden_dims: dict, output_dims: dict,
+                 act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), improved=False, dropout=0.1):
+        super().__init__()
+        self._build(n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in, act_fn_out, improved, dropout)
+
+    def forward(self, X, E, y, node_mask):
+        self._check(X)
+        pm = self._pack(X.device)
+        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask)
+        yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
+        return Xo, Eo, yo, node_mask
+
+
+class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
+    def __init__(self, n_layers: int, input_dims: dict, hidden_mlp_dims: dict, hidden_dims: dict, output_dims: dict,
+                 act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), pos_emb_permutations: int = 0, improved=False, dropout=0.1,
+                 p_to_r_skip_connection=False, p_to_r_init=10., alignment_type='old', input_alignment=False):
+        super().__init__()
+        if input_alignment:
+            raise NotImplementedError('input_alignment=True is off in both align_* experiments and is not built')
+        if p_to_r_skip_connection and alignment_type != 'correct':
+            raise NotImplementedError("alignment_type='old' is not built (align_absorbing uses 'correct')")
+        self.pos_emb_permutations = pos_emb_permutations
+        self.p_to_r_skip_connection = p_to_r_skip_connection
+        self.alignment_type = alignment_type
+        self.input_alignment = input_alignment
+        self._build(n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in, act_fn_out, improved, dropout)
+        if p_to_r_skip_connection:
+            self.skip_scaling = nn.Parameter(torch.tensor([p_to_r_init], dtype=torch.float))
+            self.skip_scaling_2 = nn.Parameter(torch.tensor([p_to_r_init], dtype=torch.float))
+            self.skip_scaling_3 = nn.Parameter(torch.tensor([1.], dtype=torch.float))
+
+    def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments):
+        assert atom_map_numbers is not None
+        self._check(X)
+        pm = self._pack(X.device)
+        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
+                                          use_skip=self.p_to_r_skip_connection)
+        yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
+        return Xo, Eo, yo, node_mask
