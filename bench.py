@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reverse-diffusion graph-steps/sec (align_absorbing) on N MI355X GPUs of one node.
+
+One "step" = one reverse step of sample_one_batch for one batch of padded reaction graphs resident in HBM:
+denoiser forward (9-layer align_absorbing graph transformer, bf16 MFMA) + fused posterior / categorical draw /
+apply_mask.  Workload = BASELINE.json configs[1]: batch 64 per GPU padded to MAX_ATOMS_RXN = 300 (synthetic 'full'
+graphs, P = 142, random-init weights: no checkpoint/dataset exists offline).  Conditions x samples are sharded over
+ranks with no collective in the data path (weak scaling); value = graphs * steps * ranks / max-over-ranks time.
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace as ns
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+FULL = dict(n_layers=9, hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
+            hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def make_cfg(dims, T=500, T_eval=100):
+    return ns(diffusion=ns(diffusion_steps=T, diffusion_steps_eval=T_eval, transition='absorbing_masknoedge',
+                           mask_nodes='product_and_sn', mask_edges='product_and_sn', node_states_to_mask=['SuNo', 'none'],
+                           edge_states_to_mask=['mol', 'within', 'across'], diffuse_nodes=True, diffuse_edges=True,
+                           temperature_scaling_node=1.0, temperature_scaling_edge=1.0, classifier_free_guidance=False,
+                           lambda_train=[5, 0], lambda_test=1, ce_lambda=2, denoiser='neuralnet', diffusion_noise_schedule='cosine'),
+              neuralnet=ns(architecture='with_y_atommap_number_pos_enc', n_layers=dims['n_layers'], hidden_dims=dims['hidden_dims'],
+                           hidden_mlp_dims=dims['hidden_mlp_dims'], dropout=0.2, improved=False, extra_features=True,
+                           pos_encoding_type='laplacian_pos_enc', p_to_r_skip_connection=True, p_to_r_init=1.0,
+                           alignment_type='correct', input_alignment=False, increase_y_dim_for_multigpu=True, use_ema=False,
+                           pos_emb_permutations=0),
+              train=ns(loss='ce'), test=ns(with_denoising=True, loss_0_repeat=1))
+
+
+def make_info():
+    from diffalign_amd.synthetic import ATOM_DECODER, BOND_DECODER
+    return ns(atom_decoder=list(ATOM_DECODER), bond_decoder=list(BOND_DECODER),
+              input_dims={'X': len(ATOM_DECODER), 'E': len(BOND_DECODER), 'y': 1},
+              output_dims={'X': len(ATOM_DECODER), 'E': len(BOND_DECODER), 'y': 0}, nodes_dist=None,
+              node_types=torch.ones(len(ATOM_DECODER)), edge_types=torch.ones(len(BOND_DECODER)))
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, oracle/oracle.py) timed on this host: same network, same step,
+    a bounded sample of the workload (B=2 graphs, n=96 nodes, one reverse step)."""
+    from oracle import oracle as O
+    from diffalign_amd import synthetic as S
+    from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
+    import torch.nn as nn
+    cores = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
+    torch.set_num_threads(cores)
+    B, n = 2, 96
+    torch.manual_seed(0)
+    KX, KE = len(S.ATOM_DECODER), len(S.BOND_DECODER)
+    m = GraphTransformerWithYAtomMapPosEmb(9, {'X': KX + 8, 'E': KE, 'y': 13}, FULL['hidden_mlp_dims'], FULL['hidden_dims'],
+                                           {'X': KX, 'E': KE, 'y': 1}, nn.ReLU(), nn.ReLU(), p_to_r_skip_connection=True,
+                                           p_to_r_init=1.0, alignment_type='correct')
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    true = S.make_reaction_batch(B, n, seed=1, P=40)
+    zt = S.noised_state(true, t=50, T=100, abs_x=S.IDX_AU, seed=2)
+    g = torch.Generator().manual_seed(3)
+    X = torch.cat([zt['X'], torch.rand(B, n, 8, generator=g)], -1)
+    y = torch.cat([zt['y'], torch.rand(B, 12, generator=g)], -1)
+    pos = S.shared_pos_encodings(true, 256, seed=4)
+    tabs = O.absorbing_tables(100, KX, KE, 1, S.IDX_AU, 0, [KX - 1, 0], [4, 5, 6])
+    mx, me = O.free_masks(true['X'], true['node_mask'], true['atom_map_numbers'], 'product_and_sn', S.IDX_SUNO)
+    qX, qE = S.exp_noise((B, n, KX), 5), S.exp_noise((B, n, n, KE), 6)
+    steps, t0 = 0, time.time()
+    with torch.no_grad():
+        while True:
+            lX, lE, _ = O.denoiser_forward(sd, X, zt['E'], y, zt['node_mask'], 9, 8, (KX, KE, 1), zt['atom_map_numbers'], pos,
+                                           zt['mol_assignments'], True)
+            O.reverse_step(lX, lE, zt['X'], zt['E'], zt['node_mask'], tabs, 50, true['X'], true['E'], mx, me, qX, qE)
+            steps += 1
+            if time.time() - t0 > seconds_budget * 0.5 or steps >= 8:
+                break
+    dt = time.time() - t0
+    return {'value': B * steps / dt, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/oracle.py (fp32 torch CPU), full align_absorbing dims, {steps} reverse step(s) of B={B} graphs at n={n} '
+                      f'in {dt:.1f}s; per-graph cost grows ~n^2, the GPU workload is n=300'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--nodes', type=int, default=300)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group('nccl', device_id=dev)
+
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S, helpers, graph, engine
+
+    B, n = args.batch, args.nodes
+    torch.manual_seed(0)                                      # weights: default nn.Linear/LayerNorm init, seed 0
+    model = DiscreteDenoisingDiffusion(make_cfg(FULL), make_info(), device=dev).eval()
+    P = (n - S.NB_DUMMY - 1) // 2
+    true = S.make_reaction_batch(B, n, seed=1 + rank, P=P)    # this rank's shard of conditions x samples
+    data = PlaceHolder(**{k: v.to(dev) for k, v in true.items()})
+    pos = S.shared_pos_encodings(true, 256, seed=3).to(dev)
+    model.pos_encodings_fn = lambda z: pos
+    g = torch.Generator().manual_seed(7)
+    xe, ye = torch.rand(B, n, 8, generator=g).to(dev), torch.rand(B, 12, generator=g).to(dev)
+    model.extra_features_fn = lambda z: (xe, ye)               # extra features are inputs
+    kx, ke = data.X.shape[-1], data.E.shape[-1]
+    T_eval = 100
+    zt0 = S.noised_state(true, t=50, T=T_eval, abs_x=S.IDX_AU, seed=11 + rank)
+    z_t = data.get_new_object(X=zt0['X'].to(dev), E=zt0['E'].to(dev), y=zt0['y'].to(dev))
+    masks = graph.get_node_masks(data, model.dataset_info.atom_decoder, model.dataset_info.bond_decoder, 'product_and_sn',
+                                 'product_and_sn')
+    tm = model.transition_model_eval
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    state = {'t': 50}
+
+    def step():
+        t = state['t']
+        t_arr = torch.full((B, 1), t, dtype=torch.long, device=dev)
+        z_t.y = t_arr.float() * 5
+        pred = model.forward(z_t, pos_encodings=pos)
+        _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_arr), tm.get_Qt_bar(t_arr - 1),
+                                                  tm.get_Qt_bar(t_arr), orig=data, node_masks=masks, generator=gen)
+        z_t.X, z_t.E = zsX, zsE
+        state['t'] = t - 1 if t > 1 else 50
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        engine.PROFILE_EVENTS = []
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+    ev = engine.PROFILE_EVENTS
+    engine.PROFILE_EVENTS = None
+    edge_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = B * args.steps * world / dt
+
+    # roofline of the dominant kernel (k_edge_layer, one launch per layer): algorithmic bytes = each 64-wide bf16 edge
+    # row read once + written once; algorithmic FLOPs = 131,072 per pair
+    pairs = B * n * n
+    bytes_launch = pairs * 64 * 2 * 2
+    flops_launch = pairs * 131072.0
+    t_s = edge_ms * 1e-3
+    tf = flops_launch / t_s / 1e12 if t_s > 0 else 0.0
+    gbs = bytes_launch / t_s / 1e9 if t_s > 0 else 0.0
+    roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
+            'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
+    if rank == 0:
+        out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+               'config': {'workload': f'align_absorbing denoiser forward + posterior/sample/mask, batch {B}/GPU padded to n={n} '
+                                      '(BASELINE.json configs[1]), 9 layers, 8.18M params, random-init weights',
+                          'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)'},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,122 @@
+"""DiscreteDenoisingDiffusion host class with the reference's constructor and method names
+(diffalign/diffusion/diffusion_abstract.py:32-372).  Device is explicit (the reference's module-level `device`
+global is gone); cfg is any attribute-style config (OmegaConf / SimpleNamespace) with the reference's keys."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import graph, helpers
+from .noise_schedule import (AbsorbingStateTransitionMaskNoEdge, DiscreteUniformTransition, MarginalUniformTransition)
+from .placeholder import PlaceHolder
+from .sampling import SamplingMixin
+from .transformer_model_with_y import GraphTransformerWithY, GraphTransformerWithYAtomMapPosEmb
+
+
+class DiscreteDenoisingDiffusion(SamplingMixin, nn.Module):
+    def __init__(self, cfg, dataset_infos, node_type_counts_unnormalized=None, edge_type_counts_unnormalized=None,
+                 use_data_parallel=None, device='cuda:0'):
+        super().__init__()
+        if use_data_parallel:
+            raise NotImplementedError('nn.DataParallel is replaced by one process per GPU (diffalign_amd.distributed)')
+        input_dims = dict(dataset_infos.input_dims)
+        output_dims = dict(dataset_infos.output_dims)
+        if cfg.neuralnet.extra_features:
+            input_dims = {'X': input_dims['X'] + 8, 'E': input_dims['E'], 'y': input_dims['y'] + 12}   # :38-40
+        self.cfg = cfg
+        self.T = cfg.diffusion.diffusion_steps
+        self.Xdim_output, self.Edim_output = output_dims['X'], output_dims['E']
+        if cfg.neuralnet.increase_y_dim_for_multigpu:
+            output_dims['y'] += 1                                                                       # :48-49
+        self.ydim_output = output_dims['y']
+        self.node_dist = getattr(dataset_infos, 'nodes_dist', None)
+        self.dataset_info = dataset_infos
+        self.eps = 1e-6
+        self.device_ = torch.device(device)
+        self.extra_features_fn = None      # callable(z_t) -> (X_extra (B,n,8), y_extra (B,12)); see compute_extra_data
+        self.pos_encodings_fn = None       # callable(z_t) -> (B,n,dx); positional encodings are an input
+        node_idx, edge_idx = graph.get_index_from_states(self.dataset_info.atom_decoder, self.dataset_info.bond_decoder,
+                                                         list(cfg.diffusion.node_states_to_mask),
+                                                         cfg.diffusion.edge_states_to_mask)
+        abs_e, abs_x = 0, self.dataset_info.atom_decoder.index('Au')                                   # :67-68
+        nn_ = cfg.neuralnet
+        if nn_.architecture == 'with_y':
+            self.model = GraphTransformerWithY(n_layers=nn_.n_layers, input_dims=input_dims, hidden_mlp_dims=nn_.hidden_mlp_dims,
+                                               hidden_dims=nn_.hidden_dims, output_dims=output_dims, act_fn_in=nn.ReLU(),
+                                               act_fn_out=nn.ReLU(), improved=nn_.improved, dropout=nn_.dropout)
+        elif nn_.architecture == 'with_y_atommap_number_pos_enc':
+            self.model = GraphTransformerWithYAtomMapPosEmb(
+                n_layers=nn_.n_layers, input_dims=input_dims, hidden_mlp_dims=nn_.hidden_mlp_dims, hidden_dims=nn_.hidden_dims,
+                output_dims=output_dims, act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), pos_emb_permutations=nn_.pos_emb_permutations,
+                improved=nn_.improved, dropout=nn_.dropout, p_to_r_skip_connection=nn_.p_to_r_skip_connection,
+                p_to_r_init=nn_.p_to_r_init, alignment_type=nn_.alignment_type, input_alignment=nn_.input_alignment)
+        else:
+            raise ValueError(f'Unknown architecture: {nn_.architecture}')
+        if cfg.neuralnet.use_ema:
+            raise NotImplementedError('EMA is off in both align_* experiments (configs/neuralnet/transformer.yaml:2)')
+        steps = [cfg.diffusion.diffusion_steps, cfg.diffusion.diffusion_steps_eval]
+        tr = cfg.diffusion.transition
+        if tr == 'uniform':
+            mk = lambda T_: DiscreteUniformTransition(cfg.diffusion.diffusion_noise_schedule, T_, self.Xdim_output, self.Edim_output,
+                                                      self.ydim_output, cfg.diffusion.diffuse_edges, node_idx, edge_idx, device)
+        elif tr == 'marginal':
+            xm = self.dataset_info.node_types.float() / self.dataset_info.node_types.float().sum()
+            em = self.dataset_info.edge_types.float() / self.dataset_info.edge_types.float().sum()
+            mk = lambda T_: MarginalUniformTransition(xm, em, self.ydim_output, cfg.diffusion.diffusion_noise_schedule, T_,
+                                                      cfg.diffusion.diffuse_edges, node_idx, edge_idx, device)
+        elif tr == 'absorbing_masknoedge':
+            mk = lambda T_: AbsorbingStateTransitionMaskNoEdge(T_, self.Xdim_output, self.Edim_output, self.ydim_output,
+                                                               cfg.diffusion.diffuse_edges, abs_x, abs_e, node_idx, edge_idx, device)
+        else:
+            raise ValueError(f'Unknown transition: {tr}')
+        self.transition_model, self.transition_model_eval = mk(steps[0]), mk(steps[1])
+        self.limit_dist = self.transition_model.get_limit_dist()
+        self.to(device)
+
+    # ---- a17 -------------------------------------------------------------------------------------------------
+    def apply_noise(self, dense_data, t_int, transition_model, noise=None):
+        """diffusion_abstract.py:227-264."""
+        assert dense_data.X.dim() == 3
+        Qtb = transition_model.get_Qt_bar(t_int)
+        pX, pE = helpers.noise_probs(dense_data, Qtb)
+        prob_t = dense_data.get_new_object(X=pX, E=pE, y=t_int.float().to(pX.device))
+        z_t = helpers.sample_discrete_features(prob=prob_t, noise=noise)
+        return z_t, prob_t
+
+    def get_pos_encodings(self, z_t):
+        if self.cfg.neuralnet.architecture != 'with_y_atommap_number_pos_enc':
+            return None
+        if self.pos_encodings_fn is None:
+            raise NotImplementedError(f"positional encodings ('{self.cfg.neuralnet.pos_encoding_type}') are an input at this "
+                                      'boundary (SURVEY §8 a13 / f-3): set model.pos_encodings_fn or pass pos_encodings')
+        return self.pos_encodings_fn(z_t)
+
+    def get_pos_encodings_if_relevant(self, z_t):
+        return self.get_pos_encodings(z_t)
+
+    def compute_extra_data(self, noisy_data):
+        """diffusion_abstract.py:350-372: concatenate the 8 node / 12 global extra features.  Computing them on the device
+        is SURVEY §8 f-1 ('next'); until then they come from `extra_features_fn` (inputs at the nn.Module boundary)."""
+        if self.extra_features_fn is None:
+            raise NotImplementedError('cfg.neuralnet.extra_features=True needs model.extra_features_fn (SURVEY §8 f-1)')
+        X_extra, y_extra = self.extra_features_fn(noisy_data)
+        return noisy_data.get_new_object(X=torch.cat((noisy_data.X, X_extra), -1), y=torch.cat((noisy_data.y, y_extra), -1))
+
+    def forward(self, z_t, use_pos_encoding_if_applicable=None, pos_encodings=None):
+        """diffusion_abstract.py:293-348 (denoiser='neuralnet').  The reference's random relabelling of atom-map
+        numbers (:297-300) is output-invariant and is skipped (it only consumes RNG and a host sync)."""
+        if self.cfg.diffusion.denoiser != 'neuralnet':
+            raise NotImplementedError("only denoiser='neuralnet' is built")
+        z_in = self.compute_extra_data(z_t) if self.cfg.neuralnet.extra_features else z_t
+        if self.cfg.neuralnet.architecture == 'with_y_atommap_number_pos_enc':
+            assert z_t.mol_assignments is not None, 'molecule_assigments is None in forward()'
+            if pos_encodings is None:
+                pos_encodings = self.get_pos_encodings(z_t)
+            if use_pos_encoding_if_applicable is not None:
+                pos_encodings = pos_encodings * use_pos_encoding_if_applicable[:, None, None].float()
+            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask, z_in.atom_map_numbers, pos_encodings,
+                                            z_in.mol_assignments)
+        else:
+            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask)
+        return PlaceHolder(X=X, E=E, y=y, node_mask=node_mask, atom_map_numbers=z_t.atom_map_numbers,
+                           mol_assignments=z_t.mol_assignments)

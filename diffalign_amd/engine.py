@@ -12,6 +12,7 @@ from . import _lib as L
 from . import pack
 
 N_STAT_CHUNKS = 32
+PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
 
 def _i(v):
@@ -115,10 +116,14 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
                            L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
     E_out = torch.empty_like(E_bf16)
     newX_in = torch.empty(R, dx, device=dev)
+    if PROFILE_EVENTS is not None:
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
     L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(qkv), _i(3 * dx), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
                               L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
                               C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe), S),
             'da_edge_layer')
+    if PROFILE_EVENTS is not None:
+        ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
     newX = torch.empty(R, dx, device=dev)
     _linear(newX_in, dx, lw['Wxo'], lw['bxo'], nm_u8, newX, dx, R, dx, dx, False)
     X1 = torch.empty(R, dx, device=dev)

@@ -525,3 +525,30 @@ def ce_loss(logits_X, logits_E, true_X, true_E, mask_x, mask_e, lambda_E: float)
     lX = F.cross_entropy(logits_X[mask_x], true_X[mask_x].argmax(-1), reduction='none')
     lE = F.cross_entropy(logits_E[me], true_E[me].argmax(-1), reduction='none')
     return lX, lE, lX.mean() + lambda_E * lE.mean()
+
+
+# --------------------------------------------------------------------------------------
+# a16 full reverse-diffusion chain (diffusion/sampling.py:11-197) with explicit noise
+# --------------------------------------------------------------------------------------
+def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tensor], T: int, T_eval: int, mask_mode: str,
+                 suno_idx: int, noise_fn, temp=(1.0, 1.0)):
+    """forward_fn(zX, zE, y) -> (logits_X, logits_E).  noise_fn(call_index, shape) -> Exp(1) noise; calls are numbered
+    in the reference's multinomial order: limit draw (X, E), then per step (X, E)."""
+    X0, E0, nm = true['X'], true['E'], true['node_mask']
+    B, n, Kx = X0.shape
+    Ke = E0.shape[-1]
+    c = 0
+    zX, zE = sample_from_limit(tabs_eval['x_limit'], tabs_eval['e_limit'], nm, noise_fn(c, (B * n, Kx)).reshape(B, n, Kx),
+                               noise_fn(c + 1, (B * n * n, Ke)).reshape(B, n, n, Ke))
+    c += 2
+    mx, me = free_masks(X0, nm, true.get('atom_map_numbers'), mask_mode, suno_idx)
+    zX, zE = apply_mask(X0, E0, zX, zE, mx, me)
+    step = T // T_eval
+    for t in range(T_eval, 0, -1):
+        y = torch.full((B, 1), float(t * step))
+        lX, lE = forward_fn(zX, zE, y)
+        qX = noise_fn(c, (B * n, Kx)).reshape(B, n, Kx)
+        qE = noise_fn(c + 1, (B * n * n, Ke)).reshape(B, n, n, Ke)
+        c += 2
+        _, _, zX, zE = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
+    return zX, zE

@@ -8,10 +8,11 @@ NOISE_BASE = 90_000
 
 
 def tiny_dims():
-    """BASELINE.json configs[0]: tiny 2-layer graph transformer."""
+    """BASELINE.json configs[0]: tiny 2-layer graph transformer (widths are multiples of 32 so the same config also
+    runs through the MFMA kernels)."""
     return dict(n_layers=2,
-                hidden_dims={'dx': 32, 'de': 8, 'dy': 8, 'n_head': 4, 'dim_ffX': 32, 'dim_ffE': 16, 'dim_ffy': 16},
-                hidden_mlp_dims={'X': 32, 'E': 16, 'y': 16})
+                hidden_dims={'dx': 64, 'de': 32, 'dy': 32, 'n_head': 4, 'dim_ffX': 64, 'dim_ffE': 64, 'dim_ffy': 64},
+                hidden_mlp_dims={'X': 64, 'E': 32, 'y': 32})
 
 
 def init_state_dict(shapes, seed):

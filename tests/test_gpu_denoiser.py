@@ -21,7 +21,7 @@ T = lambda a: torch.from_numpy(np.asarray(a))
 D = 'cuda:0'
 FULL = dict(hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
             hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
-TINY = dict(hidden_dims={'dx': 64, 'de': 32, 'dy': 16, 'n_head': 4, 'dim_ffX': 64, 'dim_ffE': 64, 'dim_ffy': 64},
+TINY = dict(hidden_dims={'dx': 64, 'de': 32, 'dy': 32, 'n_head': 4, 'dim_ffX': 64, 'dim_ffE': 64, 'dim_ffy': 64},
             hidden_mlp_dims={'X': 64, 'E': 32, 'y': 32})
 IN_DIMS = {'X': KX + 8, 'E': KE, 'y': 13}
 OUT_DIMS = {'X': KX, 'E': KE, 'y': 1}

@@ -1,0 +1,100 @@
+"""GPU: the reverse-diffusion loop (SamplingMixin.sample_one_batch mirror) against the reference's golden chain
+(BASELINE.json configs[0]) and size-independent properties at MAX_ATOMS_RXN."""
+from types import SimpleNamespace as ns
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden.common import load, weights_of, counter_noise, tiny_dims, ATOMS, BONDS
+
+pytestmark = pytest.mark.gpu
+KX, KE = len(ATOMS), len(BONDS)
+T = lambda a: torch.from_numpy(np.asarray(a))
+D = 'cuda:0'
+
+
+def make_cfg(dims, T_=10, T_eval=10, extra=False):
+    return ns(diffusion=ns(diffusion_steps=T_, diffusion_steps_eval=T_eval, transition='absorbing_masknoedge',
+                           mask_nodes='product_and_sn', mask_edges='product_and_sn', node_states_to_mask=['SuNo', 'none'],
+                           edge_states_to_mask=['mol', 'within', 'across'], diffuse_nodes=True, diffuse_edges=True,
+                           temperature_scaling_node=1.0, temperature_scaling_edge=1.0, classifier_free_guidance=False,
+                           lambda_train=[5, 0], lambda_test=1, ce_lambda=2, denoiser='neuralnet',
+                           diffusion_noise_schedule='cosine'),
+              neuralnet=ns(architecture='with_y_atommap_number_pos_enc', n_layers=dims['n_layers'], hidden_dims=dims['hidden_dims'],
+                           hidden_mlp_dims=dims['hidden_mlp_dims'], dropout=0.0, improved=False, extra_features=extra,
+                           pos_encoding_type='laplacian_pos_enc', p_to_r_skip_connection=True, p_to_r_init=1.0,
+                           alignment_type='correct', input_alignment=False, increase_y_dim_for_multigpu=True, use_ema=False,
+                           pos_emb_permutations=0),
+              train=ns(loss='ce'), test=ns(with_denoising=True, loss_0_repeat=1))
+
+
+def make_info():
+    return ns(atom_decoder=list(ATOMS), bond_decoder=list(BONDS), input_dims={'X': KX, 'E': KE, 'y': 1},
+              output_dims={'X': KX, 'E': KE, 'y': 0}, nodes_dist=None, node_types=torch.ones(KX), edge_types=torch.ones(KE))
+
+
+def test_chain_config0_against_reference_golden():
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    z = load('chain_elbo_tiny')
+    model = DiscreteDenoisingDiffusion(make_cfg(tiny_dims()), make_info(), device=D).eval()
+    model.model.load_state_dict(weights_of(z))
+    am = T(z['am'])
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=am), 64, seed=73).to(D)
+    model.pos_encodings_fn = lambda zt: pos
+    data = PlaceHolder(X=F.one_hot(T(z['true_X']), KX).float().to(D), E=F.one_hot(T(z['true_E']), KE).float().to(D),
+                       y=torch.zeros(4, 1, device=D), node_mask=T(z['node_mask']).to(D), atom_map_numbers=am.to(D),
+                       mol_assignments=T(z['mol']).to(D))
+    # one step, teacher-forced on the reference's z_t: logits within the bf16 tolerance
+    zt = data.get_new_object(X=F.one_hot(T(z['step_zt_X']), KX).float().to(D), E=F.one_hot(T(z['step_zt_E']), KE).float().to(D),
+                             y=torch.full((4, 1), 6.0, device=D))
+    with torch.no_grad():
+        pred = model.forward(zt, pos_encodings=pos)
+    rel = lambda a, b: ((a.cpu().double() - b.double()).norm() / b.double().norm()).item()
+    assert rel(pred.X, T(z['step_logit_X'])) <= 2e-2 and rel(pred.E, T(z['step_logit_E'])) <= 2e-2
+    # the full 10-step chain with the reference's noise: bf16 logits may flip near-tie draws, so agreement is
+    # statistical (the oracle, in fp32, reproduces this chain bit for bit: tests/test_oracle_golden.py)
+    out = model.sample_one_batch(data=data, noise_fn=lambda c, shp: counter_noise(shp, c))
+    gx, ge = out.X.argmax(-1).cpu().numpy(), out.E.argmax(-1).cpu().numpy()
+    ax, ae = (gx == z['chain_X']).mean(), (ge == z['chain_E']).mean()
+    assert ax >= 0.9 and ae >= 0.97, (ax, ae)
+    assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
+
+
+def test_sampling_properties_at_max_atoms():
+    """n = 300 (MAX_ATOMS_RXN), full dims, 2 layers, 3 steps: condition untouched, symmetric one-hot output, and the
+    same seed gives the same chain (determinism of the whole HIP path)."""
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    dims = dict(n_layers=2, hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
+                hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
+    torch.manual_seed(0)
+    model = DiscreteDenoisingDiffusion(make_cfg(dims, T_=500, T_eval=5, extra=True), make_info(), device=D).eval()
+    B, n = 2, 300
+    true = S.make_reaction_batch(B, n, seed=5, P=None)
+    pos = S.shared_pos_encodings(true, 256, seed=6).to(D)
+    model.pos_encodings_fn = lambda zt: pos
+    g = torch.Generator().manual_seed(7)
+    xe, ye = torch.rand(B, n, 8, generator=g).to(D), torch.rand(B, 12, generator=g).to(D)
+    model.extra_features_fn = lambda zt: (xe, ye)
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    outs = []
+    for _ in range(2):
+        outs.append(model.sample_one_batch(data=data, noise_fn=lambda c, shp: S.exp_noise(shp, 100 + c)))
+    a, b = outs
+    assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E)
+    assert torch.equal(a.E, a.E.transpose(1, 2))
+    assert bool((a.X.sum(-1) == 1).all()) and bool((a.E.sum(-1) == 1).all())
+    cls = true['X'].argmax(-1)
+    ar = torch.arange(n)[None].expand(B, n)
+    spos = torch.where(cls == 28, ar, torch.full_like(ar, -1)).max(-1).values
+    fixed = ar >= spos[:, None]                      # SuNo, product, padding: never touched
+    assert torch.equal(a.X.cpu()[fixed], true['X'][fixed])
+    fe = fixed[:, :, None] | fixed[:, None, :]
+    assert torch.equal(a.E.cpu()[fe], true['E'][fe])
+    pad = ~true['node_mask']
+    assert bool((a.X.cpu()[pad].argmax(-1) == 0).all())

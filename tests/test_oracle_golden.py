@@ -154,3 +154,31 @@ def test_posterior_and_draws(fam, t):
     qE = counter_noise((B * n * n, KE), c + 1).reshape(B, n, n, KE)
     Xs, Es = O.sample_discrete(T(z[k + 'prob_X']), T(z[k + 'prob_E']), nm, qX, qE)
     assert np.array_equal(Xs.numpy(), z[k + 'zs_X']) and np.array_equal(Es.numpy(), z[k + 'zs_E'])
+
+
+def _tiny_setup():
+    from diffalign_amd import synthetic as S
+    z = load('chain_elbo_tiny')
+    sd = weights_of(z)
+    true = dict(X=F.one_hot(T(z['true_X']), KX).float(), E=F.one_hot(T(z['true_E']), KE).float(), node_mask=T(z['node_mask']),
+                atom_map_numbers=T(z['am']), mol_assignments=T(z['mol']))
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=true['atom_map_numbers']), 64, seed=73)
+    L_, H = int(z['n_layers']), int(z['n_head'])
+
+    def fwd(zX, zE, y):
+        r = O.denoiser_forward(sd, zX, zE, y, true['node_mask'], L_, H, (KX, KE, 1), true['atom_map_numbers'], pos,
+                               true['mol_assignments'], True)
+        return r[0], r[1]
+    return z, sd, true, fwd
+
+
+def test_single_step_logits_and_chain_config0():
+    """BASELINE.json configs[0]: tiny 2-layer model, 10-step absorbing reverse diffusion on 4 synthetic graphs."""
+    z, sd, true, fwd = _tiny_setup()
+    lX, lE = fwd(F.one_hot(T(z['step_zt_X']), KX).float(), F.one_hot(T(z['step_zt_E']), KE).float(), torch.full((4, 1), 6.0))
+    close(lX, z['step_logit_X'], 1e-4); close(lE, z['step_logit_E'], 1e-4)
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    zX, zE = O.sample_chain(fwd, true, tabs, 10, 10, 'product_and_sn', 28, lambda c, shp: counter_noise(shp, c))
+    assert int(z['chain_noise_calls']) == 22
+    assert np.array_equal(zX.argmax(-1).numpy(), z['chain_X'])
+    assert np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
