@@ -139,15 +139,41 @@ __global__ void k_align_index(const int64_t* am, const int64_t* mol, int* src, i
 
 // ---------------------------------------------------------------------------------------------------
 // y path.  One workgroup (256 threads) per graph; vectors live in LDS.
-// wave-cooperative mat-vec: out[o] = act(b[o] + sum_k W[o*ldw + k] * v[k])
+// mat-vec helpers.  Every load chain is independent (no load->reduce->next-load serialisation):
+//  * block_matvec:   W row-major [O][K], one THREAD per output, 16-byte loads along K (K % 4 == 0), for small K
+//  * block_matvec_T: W stored transposed [K][O] (pack.py), threads = (output, K-slice): coalesced along O, partial
+//                    sums combined through LDS `scratch` (>= blockDim.x floats), for large K
 __device__ __forceinline__ void block_matvec(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                                              const float* v, float* out, int O, int K, bool relu, float addc = 0.f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int o = wave; o < O; o += nw) {
-    float s = 0.f;
-    for (int k = lane; k < K; k += 64) s = fmaf(W[(size_t)o * ldw + k], v[k], s);
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if (lane == 0) { s += (bias ? bias[o] : 0.f) + addc; out[o] = relu ? fmaxf(s, 0.f) : s; }
+  for (int o = threadIdx.x; o < O; o += blockDim.x) {
+    const float* w = W + (size_t)o * ldw;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    const bool vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+    for (; vec && k + 4 <= K; k += 4) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + k);
+      s0 = fmaf(ww.x, v[k], s0); s1 = fmaf(ww.y, v[k + 1], s1); s2 = fmaf(ww.z, v[k + 2], s2); s3 = fmaf(ww.w, v[k + 3], s3);
+    }
+    for (; k < K; ++k) s0 = fmaf(w[k], v[k], s0);
+    float s = (s0 + s1) + (s2 + s3) + (bias ? bias[o] : 0.f) + addc;
+    out[o] = relu ? fmaxf(s, 0.f) : s;
+  }
+}
+__device__ __forceinline__ void block_matvec_T(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
+                                               float* out, float* scratch, int O, int K, bool relu) {
+  // requires blockDim.x % O == 0
+  const int slices = blockDim.x / O, o = threadIdx.x % O, sl = threadIdx.x / O;
+  const int per = (K + slices - 1) / slices, k0 = sl * per, k1 = min(K, k0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  int k = k0;
+  for (; k + 2 <= k1; k += 2) { s0 = fmaf(WT[(size_t)k * O + o], v[k], s0); s1 = fmaf(WT[(size_t)(k + 1) * O + o], v[k + 1], s1); }
+  if (k < k1) s0 = fmaf(WT[(size_t)k * O + o], v[k], s0);
+  scratch[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < O) {
+    float s = bias ? bias[o] : 0.f;
+    for (int q = 0; q < slices; ++q) s += scratch[q * O + o];
+    out[o] = relu ? fmaxf(s, 0.f) : s;
   }
 }
 __device__ __forceinline__ void block_layernorm(const float* x, const float* g, const float* b, float* out, int D) {
@@ -201,13 +227,26 @@ __global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
 }
 
 struct YUpdArgs {
-  const float* y; const float* X; const uint8_t* nm; const float* estats;   // estats: (B,nchunk,4,de) partials
-  const float *Wxy, *bxy, *Wey, *bey;                 // x_y.lin (dy,4dx), e_y.lin (dy,4de)
+  const float* y; const float* xstats; const float* estats;   // partials (B,nchunk,4,d): sum, sum of squares, min, max
+  const float *WxyT, *bxy, *WeyT, *bey;               // x_y.lin^T (4dx,dy), e_y.lin^T (4de,dy)
   const float *Wo0, *bo0, *Wo2, *bo2;                 // y_out.0 / .2
-  const float *n1g, *n1b, *W1, *b1, *W2, *b2, *n2g, *n2b;   // norm_y1, lin_y1 (dff,dy), lin_y2 (dy,dff), norm_y2
+  const float *n1g, *n1b, *W1, *b1, *W2T, *b2, *n2g, *n2b;   // norm_y1, lin_y1 (dff,dy), lin_y2^T (dff,dy), norm_y2
   float* out;
-  int n, dx, de, dy, dff, nchunk;
+  int n, dx, de, dy, dff, nchunk_x, nchunk_e;
 };
+__device__ __forceinline__ void pooled_stats(const float* part, int nchunk, int d, double N, float* dst) {
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = part + (size_t)k * 4 * d;
+      s += p[c]; q += p[d + c]; mn = fminf(mn, p[2 * d + c]); mx = fmaxf(mx, p[3 * d + c]);
+    }
+    const double mean = s / N;
+    double var = N > 1 ? (q - N * mean * mean) / (N - 1) : 0.0;
+    if (var < 0) var = 0;
+    dst[c] = (float)mean; dst[d + c] = mn; dst[2 * d + c] = mx; dst[3 * d + c] = (float)sqrt(var);
+  }
+}
 // new_y = y_out(y + Xtoy(X) + Etoy(E)); y = LN(y+new_y); y = LN(y + lin_y2(relu(lin_y1(y))))
 // (layers.py:15-47,277-281,346-359).  Statistics run over ALL n nodes / n^2 pairs (padding included), std unbiased.
 __global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
@@ -218,31 +257,15 @@ __global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
   float* v1 = v0 + a.dy;                // dy
   float* v2 = v1 + a.dy;                // dy
   float* hb = v2 + a.dy;                // dff
+  float* scr = hb + a.dff;              // 256
   const int b = blockIdx.x, n = a.n;
-  for (int c = threadIdx.x; c < a.dx; c += blockDim.x) {
-    const float* xp = a.X + (size_t)b * n * a.dx + c;
-    double s = 0.0; float mn = INFINITY, mx = -INFINITY;
-    for (int i = 0; i < n; ++i) { const float x = xp[(size_t)i * a.dx]; s += x; mn = fminf(mn, x); mx = fmaxf(mx, x); }
-    const double mean = s / n;
-    double q = 0.0;
-    for (int i = 0; i < n; ++i) { const double d = xp[(size_t)i * a.dx] - mean; q += d * d; }
-    sx[c] = (float)mean; sx[a.dx + c] = mn; sx[2 * a.dx + c] = mx; sx[3 * a.dx + c] = n > 1 ? (float)sqrt(q / (n - 1)) : 0.f;
-  }
-  for (int c = threadIdx.x; c < a.de; c += blockDim.x) {
-    double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
-    for (int k = 0; k < a.nchunk; ++k) {
-      const float* p = a.estats + ((size_t)(b * a.nchunk + k) * 4) * a.de;
-      s += p[c]; q += p[a.de + c]; mn = fminf(mn, p[2 * a.de + c]); mx = fmaxf(mx, p[3 * a.de + c]);
-    }
-    const double N = (double)n * n, mean = s / N;
-    double var = N > 1 ? (q - N * mean * mean) / (N - 1) : 0.0;
-    if (var < 0) var = 0;
-    se[c] = (float)mean; se[a.de + c] = mn; se[2 * a.de + c] = mx; se[3 * a.de + c] = (float)sqrt(var);
-  }
+  pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx);
+  pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se);
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v0[k] = a.y[(size_t)b * a.dy + k];
   __syncthreads();
-  block_matvec(a.Wxy, 4 * a.dx, a.bxy, sx, v1, a.dy, 4 * a.dx, false);
-  block_matvec(a.Wey, 4 * a.de, a.bey, se, v2, a.dy, 4 * a.de, false);
+  block_matvec_T(a.WxyT, a.bxy, sx, v1, scr, a.dy, 4 * a.dx, false);
+  __syncthreads();
+  block_matvec_T(a.WeyT, a.bey, se, v2, scr, a.dy, 4 * a.de, false);
   __syncthreads();
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] = v0[k] + v1[k] + v2[k];
   __syncthreads();
@@ -255,11 +278,25 @@ __global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
   block_layernorm(v1, a.n1g, a.n1b, v0, a.dy);       // v0 = y after norm_y1
   block_matvec(a.W1, a.dy, a.b1, v0, hb, a.dff, a.dy, true);
   __syncthreads();
-  block_matvec(a.W2, a.dff, a.b2, hb, v1, a.dy, a.dff, false);
+  block_matvec_T(a.W2T, a.b2, hb, v1, scr, a.dy, a.dff, false);
   __syncthreads();
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
   __syncthreads();
   block_layernorm(v1, a.n2g, a.n2b, a.out + (size_t)b * a.dy, a.dy);
+}
+
+// pooled statistics partials of X (Xtoy, layers.py:15-29): out[b][chunk][4][D] over the chunk's rows (padding included)
+__global__ void __launch_bounds__(256) k_x_stats(const float* X, float* out, int n, int D, int nchunk) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int per = (n + nchunk - 1) / nchunk, i0 = ch * per, i1 = min(n, i0 + per);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float s = 0.f, q = 0.f, mn = INFINITY, mx = -INFINITY;
+    const float* xp = X + ((size_t)b * n) * D + c;
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) { const float x = xp[(size_t)i * D]; s += x; q = fmaf(x, x, q); mn = fminf(mn, x); mx = fmaxf(mx, x); }
+    float* o = out + ((size_t)(b * nchunk + ch) * 4) * D;
+    o[c] = s; o[D + c] = q; o[2 * D + c] = mn; o[3 * D + c] = mx;
+  }
 }
 
 // ===================================================================================================
@@ -340,13 +377,22 @@ int da_y_film(const float* y, const float* const* w /* 10 pointers, YFilmArgs or
   return DA_OK;
 }
 
-int da_y_update(const float* y, const float* X, const uint8_t* node_mask, const float* estats,
+int da_x_stats(const float* X, float* partials, int B, int n, int D, int nchunk, void* stream) {
+  DA_CHECK_ARG(nchunk >= 1, "da_x_stats: nchunk < 1");
+  if (B == 0 || n == 0) return DA_OK;
+  k_x_stats<<<dim3(nchunk, B), 256, 0, (hipStream_t)stream>>>(X, partials, n, D, nchunk);
+  DA_CHECK_LAUNCH("da_x_stats");
+  return DA_OK;
+}
+
+int da_y_update(const float* y, const float* xstats, const float* estats,
                 const float* const* w /* 16 pointers, YUpdArgs order */, float* out, int B, int n, int dx, int de, int dy,
-                int dff, int nchunk, void* stream) {
+                int dff, int nchunk_x, int nchunk_e, void* stream) {
+  DA_CHECK_ARG(dy > 0 && 256 % dy == 0, "da_y_update: dy=%d must divide 256", dy);
   if (B == 0) return DA_OK;
-  YUpdArgs a{y, X, node_mask, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
-             w[14], w[15], out, n, dx, de, dy, dff, nchunk};
-  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff) * sizeof(float);
+  YUpdArgs a{y, xstats, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+             w[14], w[15], out, n, dx, de, dy, dff, nchunk_x, nchunk_e};
+  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 256) * sizeof(float);
   k_y_update<<<B, 256, sh, (hipStream_t)stream>>>(a);
   DA_CHECK_LAUNCH("da_y_update");
   return DA_OK;

@@ -12,6 +12,7 @@ from . import _lib as L
 from . import pack
 
 N_STAT_CHUNKS = 32
+N_XSTAT_CHUNKS = 8
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
 
@@ -70,10 +71,11 @@ class PackedModel:
             film = [f32(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
                                             '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias',
                                             '.e_out.weight', '.e_out.bias')]
-            yup = [f32(g(k)) for k in (a + '.x_y.lin.weight', a + '.x_y.lin.bias', a + '.e_y.lin.weight', a + '.e_y.lin.bias',
-                                       a + '.y_out.0.weight', a + '.y_out.0.bias', a + '.y_out.2.weight', a + '.y_out.2.bias',
-                                       p + '.norm_y1.weight', p + '.norm_y1.bias', p + '.lin_y1.weight', p + '.lin_y1.bias',
-                                       p + '.lin_y2.weight', p + '.lin_y2.bias', p + '.norm_y2.weight', p + '.norm_y2.bias')]
+            tr = lambda t: t.detach().float().t().contiguous().to(dev)      # transposed [K][O] for block_matvec_T
+            yup = [tr(g(a + '.x_y.lin.weight')), f32(g(a + '.x_y.lin.bias')), tr(g(a + '.e_y.lin.weight')), f32(g(a + '.e_y.lin.bias')),
+                   f32(g(a + '.y_out.0.weight')), f32(g(a + '.y_out.0.bias')), f32(g(a + '.y_out.2.weight')), f32(g(a + '.y_out.2.bias')),
+                   f32(g(p + '.norm_y1.weight')), f32(g(p + '.norm_y1.bias')), f32(g(p + '.lin_y1.weight')), f32(g(p + '.lin_y1.bias')),
+                   tr(g(p + '.lin_y2.weight')), f32(g(p + '.lin_y2.bias')), f32(g(p + '.norm_y2.weight')), f32(g(p + '.norm_y2.bias'))]
             self.layers.append(dict(
                 blob=pack.edge_layer_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev),
                 Wqkv=pack.bf16_weight(Wqkv).to(dev), bqkv=f32(bqkv),
@@ -137,8 +139,10 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
     L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
             'da_add_layernorm')
     y2 = torch.empty(B, dy, device=dev)
-    L.check(lib.da_y_update(L.ptr(y), L.ptr(X), L.ptr(nm_u8), L.ptr(estats), lw['yup'].arr, L.ptr(y2), _i(B), _i(n), _i(dx),
-                            _i(de), _i(dy), _i(pm.dffy), _i(N_STAT_CHUNKS), S), 'da_y_update')
+    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, dx, device=dev)
+    L.check(lib.da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(dx), _i(N_XSTAT_CHUNKS), S), 'da_x_stats')
+    L.check(lib.da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(y2), _i(B), _i(n), _i(dx),
+                            _i(de), _i(dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(N_STAT_CHUNKS), S), 'da_y_update')
     return X2, E_out, y2
 
 
