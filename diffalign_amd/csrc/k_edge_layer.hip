@@ -13,6 +13,7 @@
 // newE^T (channels in registers, pair on the lane) -> LN1 -> FFN chained through accumulators -> LN2 -> store.
 // No LDS traffic for activations, no barriers in the main loop.
 #include "mfma_util.h"
+#include <cstdlib>
 
 template <int DE, int DX, int DFF>
 struct EdgeCfg {
@@ -51,6 +52,70 @@ struct EdgeLayerArgs {
   int B, n;
 };
 
+// One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
+// MASKED=false is the fast path for tiles whose 32 key rows all exist and are real nodes (and a real query node).
+template <int DE, int DX, int DFF, bool MASKED>
+__device__ __forceinline__ void edge_channel_block(const int cb, const int lane, const uint4 (&eraw)[DE / 16], const uint4* sW1,
+                                                   const uint4* sWO, const float* sP, const uint4 (&kv)[4],
+                                                   const float qc, const float f2c, const bool mi, const unsigned nmbits,
+                                                   const unsigned vbits, const bf16x8 id0, const bf16x8 id1, float& sm_m,
+                                                   float& sm_l, float& sm_a, f32x16 (&acc2)[DE / 32]) {
+  using C = EdgeCfg<DE, DX, DFF>;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int r = lane & 31;
+  const uint4 kf0 = kv[0], kf1 = kv[1], vf0 = kv[2], vf1 = kv[3];
+  f32x16 e1 = splat16(sP[C::P_BM1 + 32 * cb + r]);
+  f32x16 e2 = splat16(sP[C::P_BA + 32 * cb + r]);
+#pragma unroll
+  for (int s = 0; s < C::KS1; ++s) {
+    e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
+    e2 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
+  }
+  const unsigned kk[8] = {kf0.x, kf0.y, kf0.z, kf0.w, kf1.x, kf1.y, kf1.z, kf1.w};
+  const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int i2 = 0; i2 < 16; ++i2) {
+    const float kval = (i2 & 1) ? bf16_hi(kk[i2 >> 1]) : bf16_lo(kk[i2 >> 1]);
+    float y = fmaf(qc * kval, e1[i2], e2[i2]);
+    if (MASKED) {
+      const int bit = (i2 & 3) + 8 * (i2 >> 2);
+      y = (mi && ((nmbits >> bit) & 1u)) ? y : 0.f;
+      tmax = fmaxf(tmax, ((vbits >> bit) & 1u) ? y : -INFINITY);
+    } else {
+      tmax = fmaxf(tmax, y);
+    }
+    e1[i2] = y;
+  }
+  // online softmax in the log2 domain: p = 2^(y*log2e - m*log2e)
+  const float mnew = fmaxf(sm_m, tmax);
+  const float mref2 = ((MASKED && mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
+  const float sc = __builtin_amdgcn_exp2f(fmaf(sm_m, LOG2E, -mref2));
+  float psum = 0.f, pv = 0.f;
+#pragma unroll
+  for (int i2 = 0; i2 < 16; ++i2) {
+    const float vval = (i2 & 1) ? bf16_hi(vv[i2 >> 1]) : bf16_lo(vv[i2 >> 1]);
+    float p = __builtin_amdgcn_exp2f(fmaf(e1[i2], LOG2E, -mref2));
+    if (MASKED) { const int bit = (i2 & 3) + 8 * (i2 >> 2); p = ((vbits >> bit) & 1u) ? p : 0.f; }
+    psum += p;
+    pv = fmaf(p, vval, pv);
+    e1[i2] *= f2c;                                             // FiLM multiplicative part
+  }
+  sm_l = fmaf(sm_l, sc, psum);
+  sm_a = fmaf(sm_a, sc, pv);
+  sm_m = mnew;
+  // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
+  f32x16 zt = splat16(0.f);
+  zt = mfma32(pack_acc(e1, 0), id0, zt);
+  zt = mfma32(pack_acc(e1, 1), id1, zt);
+  const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
+    acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 1, lane), zb1, acc2[mt]);
+  }
+}
+
 template <int DE, int DX, int DFF, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   using C = EdgeCfg<DE, DX, DFF>;
@@ -66,12 +131,12 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const uint4* sF1 = sWO + C::WO_FR * 64;
   const uint4* sF2 = sF1 + C::F1_FR * 64;
   const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
-  // per-wave online-softmax state (running max, sum, weighted sum) per channel block, lane-private slots
-  float* sS = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (C::NCB * 3 * 64) + (threadIdx.x & 63);
+  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (2 * DX);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   constexpr int NW = NTHREADS / 64;
+  constexpr bool PREFETCH = NTHREADS <= 256;
   const int n = a.n;
   const int NT = (n + 31) / 32;
   const int R = a.B * n;
@@ -87,85 +152,83 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   for (int row = row_begin + bi * NW + wave; row < row_end; row += bpx * NW) {
     const int b = row / n, i = row - b * n;
     const bool mi = a.node_mask[row] != 0;
+    // online-softmax state per channel block (running max, sum, weighted sum): registers (the cb loop is unrolled)
+    float sm_m[C::NCB], sm_l[C::NCB], sm_a[C::NCB];
 #pragma unroll
-    for (int cb = 0; cb < C::NCB; ++cb) {
-      sS[(cb * 3 + 0) * 64] = -INFINITY; sS[(cb * 3 + 1) * 64] = 0.f; sS[(cb * 3 + 2) * 64] = 0.f;
+    for (int cb = 0; cb < C::NCB; ++cb) { sm_m[cb] = -INFINITY; sm_l[cb] = 0.f; sm_a[cb] = 0.f; }
+    // per-row lane constants (scaled query, FiLM scale) staged in this wave's LDS slice: ds_read per block instead of
+    // 2*NCB live registers (keeps the 2-waves/SIMD build free of scratch spills)
+    for (int c = lane; c < DX; c += 64) {
+      sQF[c] = a.Q[(size_t)row * a.ldq + c] * a.qscale;
+      sQF[DX + c] = a.ye2p1[(size_t)b * DX + c];
     }
-    const float* Qrow = a.Q + (size_t)row * a.ldq + r;
-    const float* F2row = a.ye2p1 + (size_t)b * DX + r;
     const bf16_t* Erow = a.E_in + (size_t)row * n * DE;
     bf16_t* Orow = a.E_out + (size_t)row * n * DE;
 
+    // E tiles: register double buffer, tile jt+1 is in flight while tile jt is processed
+    uint4 enext[C::KS1];
+    if (PREFETCH) {
+      const int j0c = min(r, n - 1);
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) enext[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
+    }
     for (int jt = 0; jt < NT; ++jt) {
       const int jl = jt * 32 + r;
       const bool jvalid = jl < n;
       const int jc = jvalid ? jl : n - 1;
       // ---- E tile: this lane's pair row, 16 B per k-step, then to C-order
       uint4 eraw[C::KS1];
+      if (PREFETCH) {
 #pragma unroll
-      for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jc * DE + 16 * u + 8 * h);
+        for (int u = 0; u < C::KS1; ++u) eraw[u] = enext[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jc * DE + 16 * u + 8 * h);
+      }
+      if (PREFETCH) {
+        const int jn = min(jl + 32, n - 1);
+#pragma unroll
+        for (int u = 0; u < C::KS1; ++u) enext[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
+      }
 #pragma unroll
       for (int u = 0; u < C::KS1; ++u) row16_to_corder(eraw[u]);
       const bool mj = jvalid && (a.node_mask[b * n + jc] != 0);
-      const unsigned nmbits = (unsigned)__ballot(mj) >> (4 * h);       // bit p: key row p of this tile is a real node
-      const unsigned vbits = (unsigned)__ballot(jvalid) >> (4 * h);    // bit p: key row p exists (j < n)
-      const float pm = (mi && mj) ? 1.f : 0.f;                          // pair mask of this lane's column
+      const unsigned nm_all = (unsigned)__ballot(mj), v_all = (unsigned)__ballot(jvalid);
+      const unsigned nmbits = nm_all >> (4 * h);       // bit p: key row p of this tile is a real node
+      const unsigned vbits = v_all >> (4 * h);         // bit p: key row p exists (j < n)
+      const float pm = (mi && mj) ? 1.f : 0.f;         // pair mask of this lane's column
+      const bool fast = mi && (nm_all == 0xffffffffu); // wave-uniform
 
       f32x16 acc2[C::MT];
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) acc2[mt] = splat16(0.f);
 
-      const uint4* kvt = a.KV + ((size_t)(b * NT + jt) * C::NCB) * 4 * 64;
-#pragma unroll 1
-      for (int cb = 0; cb < C::NCB; ++cb) {
-        const float qc = Qrow[32 * cb] * a.qscale, f2c = F2row[32 * cb];
-        const float sm_m = sS[(cb * 3 + 0) * 64], sm_l = sS[(cb * 3 + 1) * 64], sm_a = sS[(cb * 3 + 2) * 64];
-        const uint4 kf0 = kvt[(cb * 4 + 0) * 64 + lane], kf1 = kvt[(cb * 4 + 1) * 64 + lane];
-        const uint4 vf0 = kvt[(cb * 4 + 2) * 64 + lane], vf1 = kvt[(cb * 4 + 3) * 64 + lane];
-        f32x16 e1 = splat16(sP[C::P_BM1 + 32 * cb + r]);
-        f32x16 e2 = splat16(sP[C::P_BA + 32 * cb + r]);
+      // K/V fragments: register double buffer, block cb+1 (or the next tile's block 0) is in flight while block cb runs
+      const uint4* kvt = a.KV + ((size_t)(b * NT + jt) * C::NCB) * 4 * 64 + lane;
+      uint4 kvA[4], kvB[4];
 #pragma unroll
-        for (int s = 0; s < C::KS1; ++s) {
-          e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
-          e2 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
+      for (int e = 0; e < 4; ++e) kvA[e] = kvt[e * 64];
+      if (fast) {
+#pragma unroll
+        for (int cb = 0; cb < C::NCB; ++cb) {
+          if (cb + 1 < C::NCB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = kvt[((cb + 1) * 4 + e) * 64];
+          }
+          edge_channel_block<DE, DX, DFF, false>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
+                                                 vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        const unsigned kk[8] = {kf0.x, kf0.y, kf0.z, kf0.w, kf1.x, kf1.y, kf1.z, kf1.w};
-        const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
-        float tmax = -INFINITY;
+      } else {
 #pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) {
-          const int bit = (i2 & 3) + 8 * (i2 >> 2);
-          const float kval = (i2 & 1) ? bf16_hi(kk[i2 >> 1]) : bf16_lo(kk[i2 >> 1]);
-          float y = fmaf(qc * kval, e1[i2], e2[i2]);
-          y = (mi && ((nmbits >> bit) & 1u)) ? y : 0.f;
-          e1[i2] = y;
-          tmax = fmaxf(tmax, ((vbits >> bit) & 1u) ? y : -INFINITY);
-        }
-        const float mnew = fmaxf(sm_m, tmax);
-        const float mref = (mnew == -INFINITY) ? 0.f : mnew;
-        const float sc = __expf(sm_m - mref);
-        float psum = 0.f, pv = 0.f;
+        for (int cb = 0; cb < C::NCB; ++cb) {
+          if (cb + 1 < C::NCB) {
 #pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) {
-          const int bit = (i2 & 3) + 8 * (i2 >> 2);
-          const float vval = (i2 & 1) ? bf16_hi(vv[i2 >> 1]) : bf16_lo(vv[i2 >> 1]);
-          const float p = ((vbits >> bit) & 1u) ? __expf(e1[i2] - mref) : 0.f;
-          psum += p;
-          pv = fmaf(p, vval, pv);
-          e1[i2] *= f2c;                                             // FiLM multiplicative part
-        }
-        sS[(cb * 3 + 0) * 64] = mnew;
-        sS[(cb * 3 + 1) * 64] = sm_l * sc + psum;
-        sS[(cb * 3 + 2) * 64] = sm_a * sc + pv;
-        // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
-        f32x16 zt = splat16(0.f);
-        zt = mfma32(pack_acc(e1, 0), id0, zt);
-        zt = mfma32(pack_acc(e1, 1), id1, zt);
-        const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
-          acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 1, lane), zb1, acc2[mt]);
+            for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = kvt[((cb + 1) * 4 + e) * 64];
+          }
+          edge_channel_block<DE, DX, DFF, true>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
+                                                vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // ---- epilogue of the tile: newE^T + bias, pair mask, residual, LN1
@@ -271,7 +334,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     // ---- end of the query row: merge the two lane halves' softmax states, write the x_out input
 #pragma unroll
     for (int cb = 0; cb < C::NCB; ++cb) {
-      const float m_ = sS[(cb * 3 + 0) * 64], l_ = sS[(cb * 3 + 1) * 64], a_ = sS[(cb * 3 + 2) * 64];
+      const float m_ = sm_m[cb], l_ = sm_l[cb], a_ = sm_a[cb];
       const float mo = __shfl_xor(m_, 32), lo = __shfl_xor(l_, 32), ao = __shfl_xor(a_, 32);
       const float M = fmaxf(m_, mo);
       const float s0 = __expf(m_ - M), s1 = __expf(mo - M);
@@ -348,19 +411,28 @@ __global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, in
 }
 
 // ===================================================================================================
-template <int DE, int DX, int DFF>
-static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+template <int DE, int DX, int DFF, int NT_>
+static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
   using C = EdgeCfg<DE, DX, DFF>;
-  constexpr int NT_ = 256;
   auto kern = k_edge_layer<DE, DX, DFF, NT_>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * C::STATE_BYTES_PER_WAVE));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * 2 * DX * 4));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set = true;
   }
-  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * C::STATE_BYTES_PER_WAVE, s>>>(a);
+  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * 2 * DX * 4, s>>>(a);
   return DA_OK;
+}
+static int g_edge_threads = 0;
+template <int DE, int DX, int DFF>
+static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+  if (g_edge_threads == 0) {
+    const char* e = getenv("DA_EDGE_THREADS");
+    g_edge_threads = (e && atoi(e) == 256) ? 256 : 512;   // default: 8 waves/workgroup = 2 waves per SIMD
+  }
+  if (g_edge_threads == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
+  return launch_edge_nt<DE, DX, DFF, 256>(a, grid_blocks, s);
 }
 
 extern "C" {
@@ -404,7 +476,7 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
                   newX_in, (const uint4*)blob, qscale, B, n};
   const int rows = B * n;
   int grid = 256;                                   // one persistent workgroup per CU
-  int need = ((rows + 3) / 4 + 7) / 8 * 8;
+  int need = ((rows + 3) / 4 + 7) / 8 * 8;   // enough workgroups for one row per wave
   if (need < grid) grid = need < 8 ? 8 : need;
   int rc;
   if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
