@@ -164,10 +164,19 @@ __device__ __forceinline__ void block_matvec_T(const float* __restrict__ WT, con
   // requires blockDim.x % O == 0
   const int slices = blockDim.x / O, o = threadIdx.x % O, sl = threadIdx.x / O;
   const int per = (K + slices - 1) / slices, k0 = sl * per, k1 = min(K, k0 + per);
-  float s0 = 0.f, s1 = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
   int k = k0;
-  for (; k + 2 <= k1; k += 2) { s0 = fmaf(WT[(size_t)k * O + o], v[k], s0); s1 = fmaf(WT[(size_t)(k + 1) * O + o], v[k + 1], s1); }
-  if (k < k1) s0 = fmaf(WT[(size_t)k * O + o], v[k], s0);
+  for (; k + 8 <= k1; k += 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = WT[(size_t)(k + u) * O + o];      // 8 independent loads in flight
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = fmaf(w[u], v[k + u], acc[u]);
+  }
+  for (; k < k1; ++k) acc[0] = fmaf(WT[(size_t)k * O + o], v[k], acc[0]);
+  const float s0 = (acc[0] + acc[1]) + (acc[2] + acc[3]), s1 = (acc[4] + acc[5]) + (acc[6] + acc[7]);
   scratch[threadIdx.x] = s0 + s1;
   __syncthreads();
   if (threadIdx.x < O) {

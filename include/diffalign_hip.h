@@ -73,6 +73,84 @@ int da_sample_discrete(const float* prob_X, const float* prob_E, const uint8_t* 
 int da_noise_probs(const float* X, const float* E, const uint8_t* node_mask, const float* Qtb_x, const float* Qtb_e,
                    float* prob_X, float* prob_E, int B, int n, int kx, int ke, void* stream);
 
+/* ---- L2 denoiser (graph transformer) -------------------------------------------------------------------------------
+ * Hidden edge features travel between these calls as bf16 (B,n,n,de); node features X and globals y stay fp32.
+ * Weights arrive pre-packed by diffalign_amd/pack.py: "blob" = MFMA fragments (1 KiB each, lane-linear, bf16) followed
+ * by fp32 bias / LayerNorm vectors, in the layout documented in csrc/k_edge_layer.hip (EdgeCfg) and csrc/k_edge_io.hip
+ * (EdgeIoCfg); node-side nn.Linear weights as bf16 [N padded to 32][K padded to 16].
+ * Built shapes: (de,dx,dim_ffE,hidden_mlp E) = (64,256,128,128) [align_absorbing / align_marginal] and (32,64,64,32)
+ * [tiny test config]; anything else returns DA_ERR_UNSUPPORTED (-3) with a message. */
+
+long long da_edge_blob_bytes(int de, int dx, int dff);      /* -1 when the shape is not built */
+long long da_edge_in_blob_bytes(int de, int he);
+long long da_edge_out_blob_bytes(int de, int he);
+long long da_kv_frag_bytes(int B, int n, int dx);
+
+/* out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask): every nn.Linear of the node path -- mlp_in_X / mlp_out_X
+ * (transformer_model_with_y.py:584-585,602-603), q/k/v/x_out (layers.py:217-218,256,273), linX1/linX2 (layers.py:349).
+ * bf16 MFMA, fp32 accumulate. */
+int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float* bias, const uint8_t* rowmask, float* out,
+              int ldc, int M, int N, int K, int relu, void* stream);
+
+/* out = LayerNorm(a + b) * gamma + beta, eps 1e-5: normX1 / normX2 (layers.py:341,351). b may be NULL. */
+int da_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* out, int rows, int D,
+                     void* stream);
+
+/* X_h = encode_no_element(mlp_in_X(X) * mask) + pos_encodings, in place (transformer_model_with_y.py:661,666). */
+int da_x_in_finish(float* X_h, const uint8_t* node_mask, const float* pos_encodings /*may be NULL*/, int rows, int D,
+                   void* stream);
+
+/* E_h(bf16) = encode_no_element(mask(sym(mlp_in_E(E))))  (transformer_model_with_y.py:657-661; 1 <= de_in <= 16). */
+int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
+               int he, void* stream);
+
+/* y_h = mlp_in_y(y)  (transformer_model_with_y.py:590-591), fp32. */
+int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, float* out, int B, int din,
+            int dh, int dy, void* stream);
+
+/* Per-layer FiLM vectors from y (layers.py:245-247,268-270): ye2p1 = 1+y_e_mul(y), ebias = e_out.b + e_out.W y_e_add(y),
+ * yx1 = y_x_add(y), yx2p1 = 1+y_x_mul(y).  w = host array of 10 device pointers: y_e_add.{W,b}, y_e_mul.{W,b},
+ * y_x_add.{W,b}, y_x_mul.{W,b}, e_out.{W,b}. */
+int da_y_film(const float* y, const float* const* w /*host*/, float* ye2p1, float* ebias, float* yx1, float* yx2p1, int B,
+              int dy, int dx, int de, void* stream);
+
+/* K,V (fp32 (B*n, ldkv), masked) -> bf16 fragment layout read by da_edge_layer. */
+int da_kv_pack(const float* K, const float* V, int ldkv, void* kv_frag, int B, int n, int dx, void* stream);
+
+/* The fused edge side of one XEyTransformerLayer: NodeEdgeBlock (layers.py:204-284) + the E branch of
+ * XEyTransformerLayer.forward (layers.py:343-355) in one pass over E: E1/E2 projections, Y, per-channel softmax over
+ * keys (no key mask, as the reference), weighted V, FiLM, e_out, LN1, FFN, LN2.  Also writes newX_in = yx1 + yx2p1*wV,
+ * the input of x_out.  E_in != E_out. */
+int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* kv_frag, const uint8_t* node_mask,
+                  const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* stream);
+
+/* Pooled-statistics partials (sum, sum of squares, min, max per channel) for Etoy / Xtoy (layers.py:15-47):
+ * partials are (B, nchunk, 4, d) fp32 and are combined (fp64, unbiased std) inside da_y_update. */
+int da_edge_stats(const void* E_bf16, float* partials, int B, int n, int de, int nchunk, void* stream);
+int da_x_stats(const float* X, float* partials, int B, int n, int D, int nchunk, void* stream);
+
+/* y' of one layer: new_y = y_out(y + Xtoy(X) + Etoy(E)); y = norm_y1(y + new_y); y = norm_y2(y + lin_y2(relu(lin_y1(y))))
+ * (layers.py:277-281,346-359).  w = host array of 16 device pointers: x_y.lin.W^T, x_y.lin.b, e_y.lin.W^T, e_y.lin.b,
+ * y_out.0.{W,b}, y_out.2.{W,b}, norm_y1.{w,b}, lin_y1.{W,b}, lin_y2.W^T, lin_y2.b, norm_y2.{w,b} (^T = stored (in,out)). */
+int da_y_update(const float* y, const float* xstats, const float* estats, const float* const* w /*host*/, float* out,
+                int B, int n, int dx, int de, int dy, int dff, int nchunk_x, int nchunk_e, void* stream);
+
+/* src[b,r] = product node carrying the same atom-map number as reactant-side node r, else -1: the gather form of
+ * get_X_prods_and_E_prods_aligned + create_permutation_matrix_torch (transformer_model_with_y.py:506-555,
+ * utils/math_utils.py:3-44) for alignment_type='correct'. */
+int da_align_index(const int64_t* atom_map_numbers, const int64_t* mol_assignments, int* src, int B, int n, void* stream);
+
+/* X logits = mlp_out_X(X_h) + X_in[..., :kx] (+ skip_scaling * X_in[src])  (transformer_model_with_y.py:676,699-701). */
+int da_x_out_finish(const float* lin, int ldl, const float* X_in, int dx_in, const int* src /*may be NULL*/,
+                    const float* skip_scale, float* out, int B, int n, int kx, void* stream);
+
+/* E logits = sym((mlp_out_E(E_h) + E_in[..., :ke]) * offdiag) and, when src != NULL, the product->reactant skip:
+ * mapped pairs += skip1 * E_in[src_i, src_j], every other pair += skip2 on class 0
+ * (transformer_model_with_y.py:672-704). */
+int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
+                const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
