@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--nodes', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -146,6 +147,15 @@ def main():
                                                   tm.get_Qt_bar(t_arr), orig=data, node_masks=masks, generator=gen)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
+
+    if args.graph:
+        from diffalign_amd.graphs import GraphedReverseStep
+        gstep = GraphedReverseStep(model, data, z_t, pos, masks)
+
+        def step():                                   # same work as above, replayed as one HIP graph
+            t = state['t']
+            gstep.step(t)
+            state['t'] = t - 1 if t > 1 else 50
 
     def sync():
         if dist is not None:

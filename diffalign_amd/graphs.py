@@ -1,0 +1,62 @@
+"""One reverse-diffusion step captured in a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm).
+
+A step is ~110 kernel launches issued from Python through ctypes; replaying them as one graph removes the host launch
+gaps (about 3 ms of a 22 ms step at B=64, n=300).  Everything that changes between steps lives in static device
+buffers that are overwritten before each replay: the state z_t (updated inside the graph), the step index y and the
+six gathered transition tables."""
+from __future__ import annotations
+
+import torch
+
+from . import helpers
+from .placeholder import PlaceHolder
+
+
+class GraphedReverseStep:
+    def __init__(self, model, dense_data: PlaceHolder, z_t: PlaceHolder, pos_encodings, node_masks, temps=(1.0, 1.0),
+                 warmup: int = 2):
+        self.model, self.data, self.masks, self.temps, self.pos = model, dense_data, node_masks, temps, pos_encodings
+        dev = z_t.X.device
+        B, n, kx = z_t.X.shape
+        ke = z_t.E.shape[-1]
+        self.B = B
+        self.z = z_t.get_new_object(y=torch.zeros(B, 1, device=dev))
+        self.tabs = [torch.zeros(B, kx, kx, device=dev) for _ in range(3)] + [torch.zeros(B, ke, ke, device=dev) for _ in range(3)]
+        self.qX = torch.empty(B, n, kx, device=dev); self.qE = torch.empty(B, n, n, ke, device=dev)
+        self.tm = model.transition_model_eval
+        self.step_size = model.T // model.cfg.diffusion.diffusion_steps_eval
+        self._set_t(1)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        keepX, keepE = self.z.X.clone(), self.z.E.clone()
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        self.z.X.copy_(keepX); self.z.E.copy_(keepE)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._body()
+        self.z.X.copy_(keepX); self.z.E.copy_(keepE)
+
+    def _set_t(self, t: int):
+        t_arr = torch.full((self.B, 1), t, dtype=torch.long, device=self.z.X.device)
+        self.z.y.fill_(float(t * self.step_size))
+        Qt, Qsb, Qtb = self.tm.get_Qt(t_arr), self.tm.get_Qt_bar(t_arr - 1), self.tm.get_Qt_bar(t_arr)
+        for dst, src in zip(self.tabs, (Qt.X, Qsb.X, Qtb.X, Qt.E, Qsb.E, Qtb.E)):
+            dst.copy_(src)
+
+    def _body(self):
+        pred = self.model.forward(self.z, pos_encodings=self.pos)
+        self.qX.exponential_(1.0); self.qE.exponential_(1.0)
+        ph = lambda X, E: PlaceHolder(X=X, E=E, y=self.z.y)
+        _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, self.z, ph(self.tabs[0], self.tabs[3]), ph(self.tabs[1], self.tabs[4]),
+                                                  ph(self.tabs[2], self.tabs[5]), temperature=self.temps, noise=(self.qX, self.qE),
+                                                  orig=self.data, node_masks=self.masks)
+        self.z.X.copy_(zsX); self.z.E.copy_(zsE)
+
+    def step(self, t: int) -> PlaceHolder:
+        """z_t <- sample of p(z_{t-1} | z_t); returns the (static) state holder."""
+        self._set_t(t)
+        self.graph.replay()
+        return self.z
