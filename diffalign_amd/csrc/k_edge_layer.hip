@@ -71,6 +71,7 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
     e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
     e2 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
   }
+  __builtin_amdgcn_sched_barrier(0);
   const unsigned kk[8] = {kf0.x, kf0.y, kf0.z, kf0.w, kf1.x, kf1.y, kf1.z, kf1.w};
   const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
   float tmax = -INFINITY;
@@ -104,6 +105,7 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
   sm_l = fmaf(sm_l, sc, psum);
   sm_a = fmaf(sm_a, sc, pv);
   sm_m = mnew;
+  __builtin_amdgcn_sched_barrier(0);
   // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
   f32x16 zt = splat16(0.f);
   zt = mfma32(pack_acc(e1, 0), id0, zt);
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- epilogue of the tile: newE^T + bias, pair mask, residual, LN1
       float sum = 0.f;
 #pragma unroll
@@ -268,6 +271,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           for (int e = 0; e < 4; ++e) acc2[mt][4 * g + e] = fmaf((acc2[mt][4 * g + e] - mean1) * rstd1, g4[e], b4[e]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- FFN chained through accumulators:  H^T = relu(W1 Em^T + b1),  O^T = W2 H^T + b2
       bf16x8 emB[C::KS1];
 #pragma unroll
@@ -288,6 +292,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         hB[2 * ht + 0] = pack_acc(hacc, 0);
         hB[2 * ht + 1] = pack_acc(hacc, 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
       float sum2 = 0.f;
       f32x16 o[C::MT];
 #pragma unroll
