@@ -133,12 +133,12 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const uint4* sF1 = sWO + C::WO_FR * 64;
   const uint4* sF2 = sF1 + C::F1_FR * 64;
   const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
-  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (2 * DX);
+  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (2 * DX + DE);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   constexpr int NW = NTHREADS / 64;
-  constexpr bool PREFETCH = NTHREADS <= 256;
+  static_assert(C::NCB % 2 == 0, "K/V double buffer assumes an even number of channel blocks");
   const int n = a.n;
   const int NT = (n + 31) / 32;
   const int R = a.B * n;
@@ -158,43 +158,38 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     float sm_m[C::NCB], sm_l[C::NCB], sm_a[C::NCB];
 #pragma unroll
     for (int cb = 0; cb < C::NCB; ++cb) { sm_m[cb] = -INFINITY; sm_l[cb] = 0.f; sm_a[cb] = 0.f; }
-    // per-row lane constants (scaled query, FiLM scale) staged in this wave's LDS slice: ds_read per block instead of
-    // 2*NCB live registers (keeps the 2-waves/SIMD build free of scratch spills)
+    // per-row lane constants (scaled query, FiLM scale, e_out bias) staged in this wave's LDS slice: ds_read per block
+    // instead of 2*NCB live registers (keeps the 2-waves/SIMD build free of scratch spills)
     for (int c = lane; c < DX; c += 64) {
       sQF[c] = a.Q[(size_t)row * a.ldq + c] * a.qscale;
       sQF[DX + c] = a.ye2p1[(size_t)b * DX + c];
     }
+    if (lane < DE) sQF[2 * DX + lane] = a.ebias[(size_t)b * DE + lane];
     const bf16_t* Erow = a.E_in + (size_t)row * n * DE;
     bf16_t* Orow = a.E_out + (size_t)row * n * DE;
 
-    // E tiles: register double buffer, tile jt+1 is in flight while tile jt is processed
-    uint4 enext[C::KS1];
-    if (PREFETCH) {
+    // Software-pipelined loads, no extra registers: the E tile of pair block jt+1 is fetched into eraw as soon as the
+    // residual of block jt has consumed it (the FFN hides the HBM latency), K/V block 0 of jt+1 is fetched into kvA
+    // while the last channel block of jt runs, and the key-mask byte is fetched one tile ahead.
+    uint4 eraw[C::KS1];
+    {
       const int j0c = min(r, n - 1);
 #pragma unroll
-      for (int u = 0; u < C::KS1; ++u) enext[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
+      for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
     }
+    const uint4* kvrow = a.KV + ((size_t)b * NT * C::NCB) * 4 * 64 + lane;
+    uint4 kvA[4], kvB[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kvA[e] = kvrow[e * 64];
+    uint8_t nmb = a.node_mask[b * n + min(r, n - 1)];
     for (int jt = 0; jt < NT; ++jt) {
       const int jl = jt * 32 + r;
       const bool jvalid = jl < n;
-      const int jc = jvalid ? jl : n - 1;
-      // ---- E tile: this lane's pair row, 16 B per k-step, then to C-order
-      uint4 eraw[C::KS1];
-      if (PREFETCH) {
-#pragma unroll
-        for (int u = 0; u < C::KS1; ++u) eraw[u] = enext[u];
-      } else {
-#pragma unroll
-        for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jc * DE + 16 * u + 8 * h);
-      }
-      if (PREFETCH) {
-        const int jn = min(jl + 32, n - 1);
-#pragma unroll
-        for (int u = 0; u < C::KS1; ++u) enext[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
-      }
+      const bool mj = jvalid && (nmb != 0);
+      nmb = a.node_mask[b * n + min(jl + 32, n - 1)];
+      // ---- E tile: this lane's pair row, 16 B per k-step, to C-order
 #pragma unroll
       for (int u = 0; u < C::KS1; ++u) row16_to_corder(eraw[u]);
-      const bool mj = jvalid && (a.node_mask[b * n + jc] != 0);
       const unsigned nm_all = (unsigned)__ballot(mj), v_all = (unsigned)__ballot(jvalid);
       const unsigned nmbits = nm_all >> (4 * h);       // bit p: key row p of this tile is a real node
       const unsigned vbits = v_all >> (4 * h);         // bit p: key row p exists (j < n)
@@ -206,17 +201,13 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       for (int mt = 0; mt < C::MT; ++mt) acc2[mt] = splat16(0.f);
 
       // K/V fragments: register double buffer, block cb+1 (or the next tile's block 0) is in flight while block cb runs
-      const uint4* kvt = a.KV + ((size_t)(b * NT + jt) * C::NCB) * 4 * 64 + lane;
-      uint4 kvA[4], kvB[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) kvA[e] = kvt[e * 64];
+      const uint4* kvt = kvrow + (size_t)jt * C::NCB * 4 * 64;
+      const uint4* kvn = (jt + 1 < NT) ? kvt + C::NCB * 4 * 64 : kvt;   // last tile: harmless reload
       if (fast) {
 #pragma unroll
         for (int cb = 0; cb < C::NCB; ++cb) {
-          if (cb + 1 < C::NCB) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = kvt[((cb + 1) * 4 + e) * 64];
-          }
+          for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
           edge_channel_block<DE, DX, DFF, false>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
                                                  vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
           __builtin_amdgcn_sched_barrier(0);
@@ -224,10 +215,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       } else {
 #pragma unroll
         for (int cb = 0; cb < C::NCB; ++cb) {
-          if (cb + 1 < C::NCB) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = kvt[((cb + 1) * 4 + e) * 64];
-          }
+          for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
           edge_channel_block<DE, DX, DFF, true>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
                                                 vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
           __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +229,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 bias = *reinterpret_cast<const float4*>(a.ebias + (size_t)b * DE + 32 * mt + 8 * g + 4 * h);
+          const float4 bias = *reinterpret_cast<const float4*>(sQF + 2 * DX + 32 * mt + 8 * g + 4 * h);
           const uint4& er = eraw[2 * mt + (g >> 1)];
           const unsigned d0 = (g & 1) ? er.z : er.x, d1 = (g & 1) ? er.w : er.y;
           const float ev[4] = {bf16_lo(d0), bf16_hi(d0), bf16_lo(d1), bf16_hi(d1)};
@@ -252,6 +241,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
             sum += x;
           }
         }
+      }
+      {
+        const int jn = min(jl + 32, n - 1);             // next tile of this row (clamped; unused after the last tile)
+#pragma unroll
+        for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
       }
       const float mean1 = xhalf_sum(sum) * (1.f / DE);
       float vs = 0.f;
@@ -422,11 +416,11 @@ static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s
   auto kern = k_edge_layer<DE, DX, DFF, NT_>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * 2 * DX * 4));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * (2 * DX + DE) * 4));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set = true;
   }
-  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * 2 * DX * 4, s>>>(a);
+  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * (2 * DX + DE) * 4, s>>>(a);
   return DA_OK;
 }
 static int g_edge_threads = 0;
