@@ -54,18 +54,27 @@ struct EdgeLayerArgs {
 
 // One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
 // MASKED=false is the fast path for tiles whose 32 key rows all exist and are real nodes (and a real query node).
+// VALU diet (the kernel is VALU-issue bound, not MFMA bound):
+//  * the e_mul bias (+1) enters GEMM1 as one extra MFMA (ones column x [hi,lo] bf16 split of the bias) instead of 16 v_mov;
+//  * the e_add bias ba is dropped from Y: the per-channel softmax is shift invariant, and the FiLM product becomes
+//    Z = f2c*y' + f2c*ba (one packed fma); masked keys carry y' = -ba so that their true score is 0;
+//  * all elementwise work is written on float pairs so that it maps to v_pk_{mul,fma,add}_f32;
+//  * the high halves of the packed K/V words are used as fp32 without masking (k_kv_pack compensates the rounding).
 template <int DE, int DX, int DFF, bool MASKED>
 __device__ __forceinline__ void edge_channel_block(const int cb, const int lane, const uint4 (&eraw)[DE / 16], const uint4* sW1,
-                                                   const uint4* sWO, const float* sP, const uint4 (&kv)[4],
+                                                   const uint4* sWO, const float* sP, const unsigned* sB1, const uint4 (&kv)[4],
                                                    const float qc, const float f2c, const bool mi, const unsigned nmbits,
-                                                   const unsigned vbits, const bf16x8 id0, const bf16x8 id1, float& sm_m,
-                                                   float& sm_l, float& sm_a, f32x16 (&acc2)[DE / 32]) {
+                                                   const unsigned vbits, const bf16x8 onesA, const bf16x8 id0, const bf16x8 id1,
+                                                   float& sm_m, float& sm_l, float& sm_a, f32x16 (&acc2)[DE / 32]) {
   using C = EdgeCfg<DE, DX, DFF>;
   constexpr float LOG2E = 1.4426950408889634f;
   const int r = lane & 31;
   const uint4 kf0 = kv[0], kf1 = kv[1], vf0 = kv[2], vf1 = kv[3];
-  f32x16 e1 = splat16(sP[C::P_BM1 + 32 * cb + r]);
-  f32x16 e2 = splat16(sP[C::P_BA + 32 * cb + r]);
+  const float bac = sP[C::P_BA + 32 * cb + r];
+  const float baf = bac * f2c;
+  const uint4 bfr = {sB1[cb * 64 + lane], 0u, 0u, 0u};
+  f32x16 e1 = mfma32(onesA, frag_from_u4(bfr), splat16(0.f));
+  f32x16 e2 = splat16(0.f);
 #pragma unroll
   for (int s = 0; s < C::KS1; ++s) {
     e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
@@ -76,34 +85,53 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
   const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
   float tmax = -INFINITY;
 #pragma unroll
-  for (int i2 = 0; i2 < 16; ++i2) {
-    const float kval = (i2 & 1) ? bf16_hi(kk[i2 >> 1]) : bf16_lo(kk[i2 >> 1]);
-    float y = fmaf(qc * kval, e1[i2], e2[i2]);
+  for (int k = 0; k < 8; ++k) {
+    // K/V word order (k_kv_pack): words (2m, 2m+1) carry keys (4m, 4m+1) in their low halves and (4m+2, 4m+3) in their
+    // high halves, so both float pairs below are adjacent registers: two shifts per four keys, no other unpacking
+    const int m = k >> 1;
+    f32x2 kq;
+    if (k & 1) kq = f32x2{__builtin_bit_cast(float, kk[2 * m]), __builtin_bit_cast(float, kk[2 * m + 1])};
+    else kq = f32x2{bf16_lo(kk[2 * m]), bf16_lo(kk[2 * m + 1])};
+    kq *= qc;
+    const f32x2 a1 = {e1[2 * k], e1[2 * k + 1]}, a2 = {e2[2 * k], e2[2 * k + 1]};
+    f32x2 y = kq * a1 + a2;
     if (MASKED) {
-      const int bit = (i2 & 3) + 8 * (i2 >> 2);
-      y = (mi && ((nmbits >> bit) & 1u)) ? y : 0.f;
-      tmax = fmaxf(tmax, ((vbits >> bit) & 1u) ? y : -INFINITY);
+      const int b0 = ((2 * k) & 3) + 8 * ((2 * k) >> 2), b1 = b0 + 1;
+      y.x = (mi && ((nmbits >> b0) & 1u)) ? y.x : -bac;
+      y.y = (mi && ((nmbits >> b1) & 1u)) ? y.y : -bac;
+      tmax = fmaxf(tmax, ((vbits >> b0) & 1u) ? y.x : -INFINITY);
+      tmax = fmaxf(tmax, ((vbits >> b1) & 1u) ? y.y : -INFINITY);
     } else {
-      tmax = fmaxf(tmax, y);
+      tmax = fmaxf(tmax, fmaxf(y.x, y.y));
     }
-    e1[i2] = y;
+    e1[2 * k] = y.x; e1[2 * k + 1] = y.y;
   }
   // online softmax in the log2 domain: p = 2^(y*log2e - m*log2e)
   const float mnew = fmaxf(sm_m, tmax);
   const float mref2 = ((MASKED && mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
   const float sc = __builtin_amdgcn_exp2f(fmaf(sm_m, LOG2E, -mref2));
-  float psum = 0.f, pv = 0.f;
+  f32x2 psum = {0.f, 0.f}, pv = {0.f, 0.f};
 #pragma unroll
-  for (int i2 = 0; i2 < 16; ++i2) {
-    const float vval = (i2 & 1) ? bf16_hi(vv[i2 >> 1]) : bf16_lo(vv[i2 >> 1]);
-    float p = __builtin_amdgcn_exp2f(fmaf(e1[i2], LOG2E, -mref2));
-    if (MASKED) { const int bit = (i2 & 3) + 8 * (i2 >> 2); p = ((vbits >> bit) & 1u) ? p : 0.f; }
+  for (int k = 0; k < 8; ++k) {
+    const int m = k >> 1;
+    f32x2 v2;
+    if (k & 1) v2 = f32x2{__builtin_bit_cast(float, vv[2 * m]), __builtin_bit_cast(float, vv[2 * m + 1])};
+    else v2 = f32x2{bf16_lo(vv[2 * m]), bf16_lo(vv[2 * m + 1])};
+    const f32x2 y = {e1[2 * k], e1[2 * k + 1]};
+    const f32x2 arg = y * LOG2E - mref2;
+    f32x2 p = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    if (MASKED) {
+      const int b0 = ((2 * k) & 3) + 8 * ((2 * k) >> 2), b1 = b0 + 1;
+      p.x = ((vbits >> b0) & 1u) ? p.x : 0.f;
+      p.y = ((vbits >> b1) & 1u) ? p.y : 0.f;
+    }
     psum += p;
-    pv = fmaf(p, vval, pv);
-    e1[i2] *= f2c;                                             // FiLM multiplicative part
+    pv = p * v2 + pv;
+    const f32x2 z = y * f2c + baf;                               // FiLM multiplicative part (+ the deferred e_add bias)
+    e1[2 * k] = z.x; e1[2 * k + 1] = z.y;
   }
-  sm_l = fmaf(sm_l, sc, psum);
-  sm_a = fmaf(sm_a, sc, pv);
+  sm_l = fmaf(sm_l, sc, psum.x + psum.y);
+  sm_a = fmaf(sm_a, sc, pv.x + pv.y);
   sm_m = mnew;
   __builtin_amdgcn_sched_barrier(0);
   // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
@@ -133,7 +161,21 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const uint4* sF1 = sWO + C::WO_FR * 64;
   const uint4* sF2 = sF1 + C::F1_FR * 64;
   const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
-  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES) + (threadIdx.x >> 6) * (2 * DX + DE);
+  unsigned* sB1 = reinterpret_cast<unsigned*>(smem + C::BLOB_BYTES);          // [NCB][64] e_mul bias as a B-operand dword
+  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES + C::NCB * 256) + (threadIdx.x >> 6) * (2 * DX + DE);
+  // bias operand of the extra GEMM1 k-step: lanes 0-31 hold (hi, lo) bf16 split of bm1[32cb + r] at k = 0, 1; lanes 32-63 zero
+  for (int t = threadIdx.x; t < C::NCB * 64; t += NTHREADS) {
+    const int l = t & 63, cbb = t >> 6;
+    unsigned w = 0u;
+    if (l < 32) {
+      const float v = sP[C::P_BM1 + 32 * cbb + l];
+      const unsigned hi = pack_bf16(v, 0.f) & 0xffffu;
+      const float rest = v - __builtin_bit_cast(float, hi << 16);
+      w = hi | (pack_bf16(rest, 0.f) << 16);
+    }
+    sB1[t] = w;
+  }
+  __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -144,6 +186,9 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const int R = a.B * n;
 
   const bf16x8 id0 = ident_frag(0, r, h), id1 = ident_frag(1, r, h);
+  bf16x8 onesA;                                         // A operand with ones in the k = 0, 1 columns
+#pragma unroll
+  for (int j = 0; j < 8; ++j) onesA[j] = (h == 0 && j < 2) ? (short)0x3F80 : (short)0;
 
   // XCD-aware persistent row walk: blocks with equal blockIdx%8 share an XCD (L2); give each XCD one contiguous
   // chunk of rows so a graph's K/V fragments and Q rows stay in that L2.
@@ -208,8 +253,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         for (int cb = 0; cb < C::NCB; ++cb) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
-          edge_channel_block<DE, DX, DFF, false>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
-                                                 vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          edge_channel_block<DE, DX, DFF, false>(cb, lane, eraw, sW1, sWO, sP, sB1, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
+                                                 vbits, onesA, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -217,8 +262,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         for (int cb = 0; cb < C::NCB; ++cb) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
-          edge_channel_block<DE, DX, DFF, true>(cb, lane, eraw, sW1, sWO, sP, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
-                                                vbits, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          edge_channel_block<DE, DX, DFF, true>(cb, lane, eraw, sW1, sWO, sP, sB1, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
+                                                vbits, onesA, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -281,10 +326,9 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < C::KS1; ++s) hacc = mfma32(lds_frag(sF1, ht * C::KS1 + s, lane), emB[s], hacc);
-#pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) hacc[i2] = fmaxf(hacc[i2], 0.f);
-        hB[2 * ht + 0] = pack_acc(hacc, 0);
-        hB[2 * ht + 1] = pack_acc(hacc, 1);
+        // relu on the packed bf16 words: as 16-bit integers, negative floats (and -0) are negative -> v_pk_max_i16 with 0
+        hB[2 * ht + 0] = __builtin_elementwise_max(pack_acc(hacc, 0), (bf16x8)(short)0);
+        hB[2 * ht + 1] = __builtin_elementwise_max(pack_acc(hacc, 1), (bf16x8)(short)0);
       }
       __builtin_amdgcn_sched_barrier(0);
       float sum2 = 0.f;
@@ -348,6 +392,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 
 // K,V (fp32, natural (B,n,DX), already masked) -> bf16 fragment layout
 //   [b][jt][cb][kv][half2][lane][8]: element e of (half2,lane=(r,h)) is row 32jt + crow(8*half2+e, h), channel 32cb + r
+//   (the 8 elements are stored in the word order described in the kernel body)
 __global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, int B, int n, int DX) {
   const int NT = (n + 31) / 32, NCB = DX / 32;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,7 +410,20 @@ __global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, 
     const int j = 32 * jt + crow(8 * half2 + e, h);
     v[e] = j < n ? src[((size_t)b * n + j) * ldkv + 32 * cb + r] : 0.f;
   }
-  uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  // The edge kernel reads the high half of each word as an fp32 WITHOUT masking the low half off, so the high half is
+  // chosen such that the whole word, seen as fp32, is the value nearest to v[odd] (error <= half a bf16 ulp, as for RNE).
+  // Word order: words (2m, 2m+1) carry elements (4m, 4m+1) in their low halves and (4m+2, 4m+3) in their high halves.
+  unsigned w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mm = q >> 1, t2 = q & 1;
+    const unsigned lo = pack_bf16(v[4 * mm + t2], 0.f) & 0xffffu;
+    const unsigned tb = __builtin_bit_cast(unsigned, v[4 * mm + 2 + t2]);
+    const unsigned sgn = tb & 0x80000000u, mag = tb & 0x7fffffffu;
+    const unsigned hm = mag >= lo ? (mag - lo + 0x8000u) >> 16 : 0u;
+    w[q] = sgn | (hm << 16) | lo;
+  }
+  uint4 o = {w[0], w[1], w[2], w[3]};
   out[t] = o;
 }
 
@@ -416,11 +474,11 @@ static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s
   auto kern = k_edge_layer<DE, DX, DFF, NT_>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + (NT_ / 64) * (2 * DX + DE) * 4));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set = true;
   }
-  kern<<<grid_blocks, NT_, C::BLOB_BYTES + (NT_ / 64) * (2 * DX + DE) * 4, s>>>(a);
+  kern<<<grid_blocks, NT_, C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4, s>>>(a);
   return DA_OK;
 }
 static int g_edge_threads = 0;
