@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdiffalign_hip.so')
+# DA_LIB: developer hook for timing-experiment builds of the same library (tools/build_variant.sh)
+LIB_PATH = os.environ.get('DA_LIB') or os.path.join(_HERE, 'libdiffalign_hip.so')
 _lib: Optional[C.CDLL] = None
 
 c_f = C.c_void_p  # all device pointers travel as void*

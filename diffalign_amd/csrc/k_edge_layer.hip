@@ -15,6 +15,23 @@
 #include "mfma_util.h"
 #include <cstdlib>
 
+// Timing-experiment hooks (tools/build_variant.sh): each removes one cost to measure what it hides.  Results are WRONG
+// with any of them defined; the product build defines none.
+#ifdef EXP_NOLDS
+#define LDSF(base, frag, lane) lds_frag(base, 0, lane)
+#else
+#define LDSF(base, frag, lane) lds_frag(base, frag, lane)
+#endif
+#ifdef EXP_NOMFMA
+#define mfma32(a, b, c) fake_mfma(a, b, c)
+__device__ __forceinline__ f32x16 fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) { c[0] += (float)(a[0] ^ b[0]); return c; }
+#endif
+#ifdef EXP_NOEXP
+#define EXP2F(x) (x)
+#else
+#define EXP2F(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 template <int DE, int DX, int DFF>
 struct EdgeCfg {
   static constexpr int NCB = DX / 32;
@@ -50,6 +67,7 @@ struct EdgeLayerArgs {
   const uint4* blob;      // packed layer weights (EdgeCfg layout)
   float qscale;           // 1/sqrt(df)
   int B, n;
+  int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
 };
 
 // One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
@@ -60,30 +78,92 @@ struct EdgeLayerArgs {
 //    Z = f2c*y' + f2c*ba (one packed fma); masked keys carry y' = -ba so that their true score is 0;
 //  * all elementwise work is written on float pairs so that it maps to v_pk_{mul,fma,add}_f32;
 //  * the high halves of the packed K/V words are used as fp32 without masking (k_kv_pack compensates the rounding).
+// GEMM1 of one 32-channel block: e1 = E W_mul^T + (1 + b_mul) (bias through the ones k-step), e2 = E W_add^T
+template <int DE, int DX, int DFF>
+__device__ __forceinline__ void gemm1_block(const int cb, const int lane, const uint4 (&eraw)[DE / 16], const uint4* sW1,
+                                            const unsigned* sB1, const bf16x8 onesA, f32x16& e1, f32x16& e2) {
+  using C = EdgeCfg<DE, DX, DFF>;
+  const uint4 bfr = {sB1[cb * 64 + lane], 0u, 0u, 0u};
+  e1 = mfma32(onesA, frag_from_u4(bfr), splat16(0.f));
+  e2 = splat16(0.f);
+#pragma unroll
+  for (int s = 0; s < C::KS1; ++s) {
+    e1 = mfma32(frag_from_u4(eraw[s]), LDSF(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
+    e2 = mfma32(frag_from_u4(eraw[s]), LDSF(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
+  }
+}
+
+// transpose Z (pairs x 32 channels, in e1) -> Z^T in registers by an identity MFMA, then GEMM2: acc2 += W_out Z^T
+template <int DE, int DX, int DFF>
+__device__ __forceinline__ void gemm2_block(const int cb, const int lane, const f32x16& z, const uint4* sWO, const bf16x8 id0,
+                                            const bf16x8 id1, f32x16 (&acc2)[DE / 32]) {
+  using C = EdgeCfg<DE, DX, DFF>;
+  f32x16 zt = splat16(0.f);
+  zt = mfma32(pack_acc(z, 0), id0, zt);
+  zt = mfma32(pack_acc(z, 1), id1, zt);
+  const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    acc2[mt] = mfma32(LDSF(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
+    acc2[mt] = mfma32(LDSF(sWO, (cb * C::MT + mt) * 2 + 1, lane), zb1, acc2[mt]);
+  }
+}
+
+// Opaque use+def: the value must be computed here (keeps LLVM's IR-level sinking from moving a chunk's arithmetic
+// past the scheduling barrier that follows it; emits no instruction).
+__device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// GEMM1 of the NEXT channel block, one MFMA per call, fed into the elementwise work of the current block (below).
+// Each step issues its MFMA with the LDS fragment fetched by the previous step and fetches the next fragment.
+template <int DE, int DX, int DFF>
+struct Gemm1Feed {
+  using C = EdgeCfg<DE, DX, DFF>;
+  static constexpr int N = 1 + 2 * C::KS1;
+  const bool on;                 // false: no next block, every step is a no-op
+  const int cbn, lane;
+  const uint4 (&eraw)[DE / 16];
+  const uint4* sW1;
+  const bf16x8 onesA;
+  f32x16& f1;
+  f32x16& f2;
+  uint4 frag;                    // operand of the next step
+  __device__ __forceinline__ Gemm1Feed(bool on_, int cbn_, int lane_, const uint4 (&eraw_)[DE / 16], const uint4* sW1_,
+                                       const unsigned* sB1, bf16x8 onesA_, f32x16& f1_, f32x16& f2_)
+      : on(on_), cbn(cbn_), lane(lane_), eraw(eraw_), sW1(sW1_), onesA(onesA_), f1(f1_), f2(f2_) {
+    if (on) frag = uint4{sB1[cbn * 64 + lane], 0u, 0u, 0u};
+  }
+  __device__ __forceinline__ void step(const int i) {
+    if (!on || i >= N) return;
+    const bf16x8 w = frag_from_u4(frag);
+    if (i + 1 < N) frag = sW1[((cbn * 2 + (i & 1)) * C::KS1 + (i >> 1)) * 64 + lane];   // fragment of step i+1: (s, which) = (i>>1, i&1)
+    if (i == 0) { f1 = mfma32(onesA, w, splat16(0.f)); return; }
+    const int s2 = (i - 1) >> 1;
+    if ((i - 1) & 1) f2 = mfma32(frag_from_u4(eraw[s2]), w, i == 2 ? splat16(0.f) : f2);
+    else f1 = mfma32(frag_from_u4(eraw[s2]), w, f1);
+  }
+};
+
+// Elementwise middle of one channel block: Y, online softmax, FiLM.  In: e1, e2 (GEMM1).  Out: e1 = Z.
+// The work is cut into chunks of four keys; after each chunk one MFMA of the next block's GEMM1 is issued (feed) and a
+// scheduling barrier pins that order, so that the wave's own matrix and vector work overlap (left alone, the compiler
+// issues the nine MFMAs back to back and the ~110 VALU instructions as one run).
 template <int DE, int DX, int DFF, bool MASKED>
-__device__ __forceinline__ void edge_channel_block(const int cb, const int lane, const uint4 (&eraw)[DE / 16], const uint4* sW1,
-                                                   const uint4* sWO, const float* sP, const unsigned* sB1, const uint4 (&kv)[4],
-                                                   const float qc, const float f2c, const bool mi, const unsigned nmbits,
-                                                   const unsigned vbits, const bf16x8 onesA, const bf16x8 id0, const bf16x8 id1,
-                                                   float& sm_m, float& sm_l, float& sm_a, f32x16 (&acc2)[DE / 32]) {
+__device__ __forceinline__ void softmax_film_block(const int cb, const int lane, f32x16& e1, const f32x16& e2, const float* sP,
+                                                   uint4 (&kv)[4], const uint4* kv_next, const float qc, const float f2c,
+                                                   const bool mi, const unsigned nmbits, const unsigned vbits, float& sm_m,
+                                                   float& sm_l, float& sm_a, Gemm1Feed<DE, DX, DFF>& feed) {
   using C = EdgeCfg<DE, DX, DFF>;
   constexpr float LOG2E = 1.4426950408889634f;
   const int r = lane & 31;
-  const uint4 kf0 = kv[0], kf1 = kv[1], vf0 = kv[2], vf1 = kv[3];
   const float bac = sP[C::P_BA + 32 * cb + r];
   const float baf = bac * f2c;
-  const uint4 bfr = {sB1[cb * 64 + lane], 0u, 0u, 0u};
-  f32x16 e1 = mfma32(onesA, frag_from_u4(bfr), splat16(0.f));
-  f32x16 e2 = splat16(0.f);
-#pragma unroll
-  for (int s = 0; s < C::KS1; ++s) {
-    e1 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 0) * C::KS1 + s, lane), e1);
-    e2 = mfma32(frag_from_u4(eraw[s]), lds_frag(sW1, (cb * 2 + 1) * C::KS1 + s, lane), e2);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  const unsigned kk[8] = {kf0.x, kf0.y, kf0.z, kf0.w, kf1.x, kf1.y, kf1.z, kf1.w};
-  const unsigned vv[8] = {vf0.x, vf0.y, vf0.z, vf0.w, vf1.x, vf1.y, vf1.z, vf1.w};
+  const unsigned kk[8] = {kv[0].x, kv[0].y, kv[0].z, kv[0].w, kv[1].x, kv[1].y, kv[1].z, kv[1].w};
+  const unsigned vv[8] = {kv[2].x, kv[2].y, kv[2].z, kv[2].w, kv[3].x, kv[3].y, kv[3].z, kv[3].w};
   float tmax = -INFINITY;
+  int fs = 0;                                       // next feed step
+  feed.step(fs++);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     // K/V word order (k_kv_pack): words (2m, 2m+1) carry keys (4m, 4m+1) in their low halves and (4m+2, 4m+3) in their
@@ -104,8 +184,13 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
     } else {
       tmax = fmaxf(tmax, fmaxf(y.x, y.y));
     }
+    pin(y);
     e1[2 * k] = y.x; e1[2 * k + 1] = y.y;
+    if (k & 1) { pin(tmax); feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
   }
+#ifndef EXP_NOKV
+  kv[0] = kv_next[0]; kv[1] = kv_next[64];          // K words are dead: fetch the next block's in place
+#endif
   // online softmax in the log2 domain: p = 2^(y*log2e - m*log2e)
   const float mnew = fmaxf(sm_m, tmax);
   const float mref2 = ((MASKED && mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
@@ -119,7 +204,7 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
     else v2 = f32x2{bf16_lo(vv[2 * m]), bf16_lo(vv[2 * m + 1])};
     const f32x2 y = {e1[2 * k], e1[2 * k + 1]};
     const f32x2 arg = y * LOG2E - mref2;
-    f32x2 p = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    f32x2 p = {EXP2F(arg.x), EXP2F(arg.y)};
     if (MASKED) {
       const int b0 = ((2 * k) & 3) + 8 * ((2 * k) >> 2), b1 = b0 + 1;
       p.x = ((vbits >> b0) & 1u) ? p.x : 0.f;
@@ -127,23 +212,19 @@ __device__ __forceinline__ void edge_channel_block(const int cb, const int lane,
     }
     psum += p;
     pv = p * v2 + pv;
-    const f32x2 z = y * f2c + baf;                               // FiLM multiplicative part (+ the deferred e_add bias)
+    f32x2 z = y * f2c + baf;                                     // FiLM multiplicative part (+ the deferred e_add bias)
+    pin(z);
     e1[2 * k] = z.x; e1[2 * k + 1] = z.y;
+    if (k & 1) { pin(psum); pin(pv); feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
   }
+#pragma unroll
+  for (; fs < Gemm1Feed<DE, DX, DFF>::N; ++fs) feed.step(fs);      // (DE = 64: none left)
+#ifndef EXP_NOKV
+  kv[2] = kv_next[128]; kv[3] = kv_next[192];       // V words likewise
+#endif
   sm_l = fmaf(sm_l, sc, psum.x + psum.y);
   sm_a = fmaf(sm_a, sc, pv.x + pv.y);
   sm_m = mnew;
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- transpose Z (pairs x 32 channels) -> Z^T (32 channels x pairs) in registers
-  f32x16 zt = splat16(0.f);
-  zt = mfma32(pack_acc(e1, 0), id0, zt);
-  zt = mfma32(pack_acc(e1, 1), id1, zt);
-  const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt) {
-    acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
-    acc2[mt] = mfma32(lds_frag(sWO, (cb * C::MT + mt) * 2 + 1, lane), zb1, acc2[mt]);
-  }
 }
 
 template <int DE, int DX, int DFF, int NTHREADS>
@@ -180,7 +261,6 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   constexpr int NW = NTHREADS / 64;
-  static_assert(C::NCB % 2 == 0, "K/V double buffer assumes an even number of channel blocks");
   const int n = a.n;
   const int NT = (n + 31) / 32;
   const int R = a.B * n;
@@ -196,6 +276,10 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const int chunk = (R + 7) / 8;
   const int row_begin = xcd * chunk, row_end = min(R, row_begin + chunk);
 
+  if (wave >= NW / 2) {
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
+    for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(1);
+  }
   for (int row = row_begin + bi * NW + wave; row < row_end; row += bpx * NW) {
     const int b = row / n, i = row - b * n;
     const bool mi = a.node_mask[row] != 0;
@@ -214,8 +298,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     bf16_t* Orow = a.E_out + (size_t)row * n * DE;
 
     // Software-pipelined loads, no extra registers: the E tile of pair block jt+1 is fetched into eraw as soon as the
-    // residual of block jt has consumed it (the FFN hides the HBM latency), K/V block 0 of jt+1 is fetched into kvA
-    // while the last channel block of jt runs, and the key-mask byte is fetched one tile ahead.
+    // residual of block jt has consumed it (the FFN hides the HBM latency), the K (V) words of the next channel block
+    // replace the current ones as soon as they are dead, and the key-mask byte is fetched one tile ahead.
     uint4 eraw[C::KS1];
     {
       const int j0c = min(r, n - 1);
@@ -223,7 +307,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
     }
     const uint4* kvrow = a.KV + ((size_t)b * NT * C::NCB) * 4 * 64 + lane;
-    uint4 kvA[4], kvB[4];
+    uint4 kvA[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) kvA[e] = kvrow[e * 64];
     uint8_t nmb = a.node_mask[b * n + min(r, n - 1)];
@@ -245,25 +329,32 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) acc2[mt] = splat16(0.f);
 
-      // K/V fragments: register double buffer, block cb+1 (or the next tile's block 0) is in flight while block cb runs
       const uint4* kvt = kvrow + (size_t)jt * C::NCB * 4 * 64;
       const uint4* kvn = (jt + 1 < NT) ? kvt + C::NCB * 4 * 64 : kvt;   // last tile: harmless reload
+      // Channel blocks, software pipelined: GEMM1 of block cb+1 is issued beside the elementwise work of block cb, so the
+      // wave's own MFMAs and VALU overlap (the two waves of a SIMD do not hide each other's dependency stalls).
+      f32x16 e1, e2;
+      gemm1_block<DE, DX, DFF>(0, lane, eraw, sW1, sB1, onesA, e1, e2);
       if (fast) {
 #pragma unroll
         for (int cb = 0; cb < C::NCB; ++cb) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
-          edge_channel_block<DE, DX, DFF, false>(cb, lane, eraw, sW1, sWO, sP, sB1, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
-                                                 vbits, onesA, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          f32x16 f1, f2;
+          Gemm1Feed<DE, DX, DFF> feed(cb + 1 < C::NCB, cb + 1, lane, eraw, sW1, sB1, onesA, f1, f2);
+          softmax_film_block<DE, DX, DFF, false>(cb, lane, e1, e2, sP, kvA, (cb + 1 < C::NCB) ? kvt + (cb + 1) * 4 * 64 : kvn, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi,
+                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed);
+          gemm2_block<DE, DX, DFF>(cb, lane, e1, sWO, id0, id1, acc2);
+          if (cb + 1 < C::NCB) { e1 = f1; e2 = f2; }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
         for (int cb = 0; cb < C::NCB; ++cb) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ((cb & 1) ? kvA : kvB)[e] = (cb + 1 < C::NCB) ? kvt[((cb + 1) * 4 + e) * 64] : kvn[e * 64];
-          edge_channel_block<DE, DX, DFF, true>(cb, lane, eraw, sW1, sWO, sP, sB1, (cb & 1) ? kvB : kvA, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi, nmbits,
-                                                vbits, onesA, id0, id1, sm_m[cb], sm_l[cb], sm_a[cb], acc2);
+          f32x16 f1, f2;
+          Gemm1Feed<DE, DX, DFF> feed(cb + 1 < C::NCB, cb + 1, lane, eraw, sW1, sB1, onesA, f1, f2);
+          softmax_film_block<DE, DX, DFF, true>(cb, lane, e1, e2, sP, kvA, (cb + 1 < C::NCB) ? kvt + (cb + 1) * 4 * 64 : kvn, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi,
+                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed);
+          gemm2_block<DE, DX, DFF>(cb, lane, e1, sWO, id0, id1, acc2);
+          if (cb + 1 < C::NCB) { e1 = f1; e2 = f2; }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -289,8 +380,10 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       }
       {
         const int jn = min(jl + 32, n - 1);             // next tile of this row (clamped; unused after the last tile)
+#ifndef EXP_NOELOAD
 #pragma unroll
         for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
+#endif
       }
       const float mean1 = xhalf_sum(sum) * (1.f / DE);
       float vs = 0.f;
@@ -325,7 +418,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           hacc[4 * g + 0] = bv.x; hacc[4 * g + 1] = bv.y; hacc[4 * g + 2] = bv.z; hacc[4 * g + 3] = bv.w;
         }
 #pragma unroll
-        for (int s = 0; s < C::KS1; ++s) hacc = mfma32(lds_frag(sF1, ht * C::KS1 + s, lane), emB[s], hacc);
+        for (int s = 0; s < C::KS1; ++s) hacc = mfma32(LDSF(sF1, ht * C::KS1 + s, lane), emB[s], hacc);
         // relu on the packed bf16 words: as 16-bit integers, negative floats (and -0) are negative -> v_pk_max_i16 with 0
         hB[2 * ht + 0] = __builtin_elementwise_max(pack_acc(hacc, 0), (bf16x8)(short)0);
         hB[2 * ht + 1] = __builtin_elementwise_max(pack_acc(hacc, 1), (bf16x8)(short)0);
@@ -341,7 +434,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           o[mt][4 * g + 0] = bv.x; o[mt][4 * g + 1] = bv.y; o[mt][4 * g + 2] = bv.z; o[mt][4 * g + 3] = bv.w;
         }
 #pragma unroll
-        for (int s = 0; s < C::KSF; ++s) o[mt] = mfma32(lds_frag(sF2, mt * C::KSF + s, lane), hB[s], o[mt]);
+        for (int s = 0; s < C::KSF; ++s) o[mt] = mfma32(LDSF(sF2, mt * C::KSF + s, lane), hB[s], o[mt]);
 #pragma unroll
         for (int i2 = 0; i2 < 16; ++i2) { o[mt][i2] += acc2[mt][i2]; sum2 += o[mt][i2]; }
       }
@@ -371,7 +464,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         }
         uint4 st = {d[0], d[1], d[2], d[3]};
         row16_to_corder(st);   // involution: C-order -> natural 16 bytes at [16u + 8h]
+#ifdef EXP_NOSTORE
+        if (st.x == 0x12345678u && jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
+#else
         if (jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
+#endif
       }
     }
     // ---- end of the query row: merge the two lane halves' softmax states, write the x_out input
@@ -530,7 +627,9 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   if (B == 0 || n == 0) return DA_OK;
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n};
+                  newX_in, (const uint4*)blob, qscale, B, n, 0, 0};
+  { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
+    const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2); }
   const int rows = B * n;
   int grid = 256;                                   // one persistent workgroup per CU
   int need = ((rows + 3) / 4 + 7) / 8 * 8;   // enough workgroups for one row per wave
