@@ -7,52 +7,58 @@
 // out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask).  A fp32 (lda), W bf16 row-major [Npad][Kpad] (zero padded to
 // multiples of 32 / 16 by diffalign_amd/pack.py), out fp32 (ldc).  One wave = 32 rows x (32*NTILE) columns; fragments
 // are loaded straight from global/L2 (the operands are small and hot), no LDS.
-template <int NTILE, bool RELU>
-__global__ void __launch_bounds__(256) k_linear(const float* __restrict__ A, int lda, const bf16_t* __restrict__ W, int Kpad,
+// W is pre-packed in MFMA B-fragment order (diffalign_amd/pack.py bf16_weight): fragment (nt, ks) = 64 lanes x 8 bf16,
+// lane (r,h) element j = W[32nt + r][16ks + 8h + j]; fragments are stored [nt][ks], 1 KiB each, so a wave's operand
+// read is one coalesced 1 KiB line set.  KSMAX*16 >= Kpad: the wave's 32 activation rows are converted to bf16
+// A fragments once and stay in registers while it walks its NTILE output tiles.
+template <int NTILE, int KSMAX, bool RELU>
+__global__ void __launch_bounds__(256) k_linear(const float* __restrict__ A, int lda, const uint4* __restrict__ W, int KS,
                                                 const float* __restrict__ bias, const uint8_t* __restrict__ rowmask,
                                                 float* __restrict__ out, int ldc, int M, int N, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
-  const int n0 = blockIdx.y * 32 * NTILE;
+  const int nt0 = blockIdx.y * NTILE;
   if (m0 >= M) return;
   const int arow = min(m0 + r, M - 1);
   const float* ap = A + (size_t)arow * lda;
-  f32x16 acc[NTILE];
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t) acc[t] = splat16(0.f);
   const bool vec_ok = ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
-  for (int k0 = 0; k0 < Kpad; k0 += 16) {
-    const int kb = k0 + 8 * h;
-    float av[8];
-    if (vec_ok && kb + 8 <= K) {
-      const float4 x0 = *reinterpret_cast<const float4*>(ap + kb), x1 = *reinterpret_cast<const float4*>(ap + kb + 4);
-      av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
-    } else {
+  bf16x8 af[KSMAX];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
-    }
-    uint4 au = {pack_bf16(av[0], av[1]), pack_bf16(av[2], av[3]), pack_bf16(av[4], av[5]), pack_bf16(av[6], av[7])};
-    const bf16x8 af = frag_from_u4(au);
+  for (int s = 0; s < KSMAX; ++s) {
+    if (s < KS) {
+      const int kb = 16 * s + 8 * h;
+      float av[8];
+      if (vec_ok && kb + 8 <= K) {
+        const float4 x0 = *reinterpret_cast<const float4*>(ap + kb), x1 = *reinterpret_cast<const float4*>(ap + kb + 4);
+        av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
+      } else {
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      const uint4 wu = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + 32 * t + r) * Kpad + kb);
-      acc[t] = mfma32(af, frag_from_u4(wu), acc[t]);
+        for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
+      }
+      const uint4 au = {pack_bf16(av[0], av[1]), pack_bf16(av[2], av[3]), pack_bf16(av[4], av[5]), pack_bf16(av[6], av[7])};
+      af[s] = frag_from_u4(au);
     }
   }
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) {
-    const int col = n0 + 32 * t + r;
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
+    const uint4* wp = W + ((size_t)(nt0 + t) * KS) * 64 + lane;
+    f32x16 acc = splat16(0.f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = m0 + crow(i, h);
-      if (row >= M) continue;
-      float v = acc[t][i] + bv;
-      if (RELU) v = fmaxf(v, 0.f);
-      if (rowmask) v = rowmask[row] ? v : 0.f;
-      out[(size_t)row * ldc + col] = v;
+    for (int s = 0; s < KSMAX; ++s)
+      if (s < KS) acc = mfma32(af[s], frag_from_u4(wp[s * 64]), acc);
+    const int col = (nt0 + t) * 32 + r;
+    if (col < N) {
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + crow(i, h);
+        if (row >= M) continue;
+        float v = acc[i] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        if (rowmask) v = rowmask[row] ? v : 0.f;
+        out[(size_t)row * ldc + col] = v;
+      }
     }
   }
 }
@@ -319,19 +325,23 @@ int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float
   const bf16_t* W = (const bf16_t*)W_bf16;
   const int Npad = (N + 31) / 32 * 32;
   const int gm = (M + 127) / 128;
-  if (Npad % 128 == 0) {
-    dim3 grid(gm, Npad / 128);
-    if (relu) k_linear<4, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
-    else k_linear<4, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
-  } else if (Npad % 64 == 0) {
-    dim3 grid(gm, Npad / 64);
-    if (relu) k_linear<2, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
-    else k_linear<2, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+  const int KS = Kpad / 16;
+  const uint4* Wf = (const uint4*)W;
+#define DA_LIN(NTILE_, KSMAX_)                                                                                             \
+  do {                                                                                                                     \
+    dim3 grid(gm, Npad / (32 * NTILE_));                                                                                   \
+    if (relu) k_linear<NTILE_, KSMAX_, true><<<grid, 256, 0, s>>>(A, lda, Wf, KS, bias, rowmask, out, ldc, M, N, K);       \
+    else k_linear<NTILE_, KSMAX_, false><<<grid, 256, 0, s>>>(A, lda, Wf, KS, bias, rowmask, out, ldc, M, N, K);          \
+  } while (0)
+  if (KS <= 4) {
+    if (Npad % 128 == 0) DA_LIN(4, 4); else if (Npad % 64 == 0) DA_LIN(2, 4); else DA_LIN(1, 4);
+  } else if (KS <= 16) {
+    if (Npad % 128 == 0) DA_LIN(4, 16); else if (Npad % 64 == 0) DA_LIN(2, 16); else DA_LIN(1, 16);
   } else {
-    dim3 grid(gm, Npad / 32);
-    if (relu) k_linear<1, true><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
-    else k_linear<1, false><<<grid, 256, 0, s>>>(A, lda, W, Kpad, bias, rowmask, out, ldc, M, N, K);
+    da_set_error("da_linear: K=%d not built (K <= 256)", K);
+    return DA_ERR_UNSUPPORTED;
   }
+#undef DA_LIN
   DA_CHECK_LAUNCH("da_linear");
   return DA_OK;
 }

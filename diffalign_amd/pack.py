@@ -38,10 +38,14 @@ def _blob(frags: List[torch.Tensor], params: List[torch.Tensor]) -> torch.Tensor
 
 
 def bf16_weight(W: torch.Tensor) -> torch.Tensor:
-    """nn.Linear weight (N,K) -> bf16 (Npad32, Kpad16) for da_linear."""
+    """nn.Linear weight (N,K) -> bf16 in MFMA B-fragment order for da_linear, shape (Npad32/32 * Kpad16/16 * 64, 8) viewed
+    as (Npad32, Kpad16): fragment (nt, ks), lane (r, h), element j = W[32nt + r][16ks + 8h + j]; fragments [nt][ks]."""
     N, K = W.shape
-    Wp = _pad2(W.detach().float().cpu(), (N + 31) // 32 * 32, (K + 15) // 16 * 16)
-    return Wp.to(torch.bfloat16).contiguous()
+    Np, Kp = (N + 31) // 32 * 32, (K + 15) // 16 * 16
+    Wp = _pad2(W.detach().float().cpu(), Np, Kp).to(torch.bfloat16)
+    # (nt, r, ks, h, j) -> (nt, ks, h, r, j)
+    Wf = Wp.view(Np // 32, 32, Kp // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    return Wf.view(Np, Kp)
 
 
 def edge_layer_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:

@@ -88,7 +88,8 @@ long long da_kv_frag_bytes(int B, int n, int dx);
 
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask): every nn.Linear of the node path -- mlp_in_X / mlp_out_X
  * (transformer_model_with_y.py:584-585,602-603), q/k/v/x_out (layers.py:217-218,256,273), linX1/linX2 (layers.py:349).
- * bf16 MFMA, fp32 accumulate. */
+ * bf16 MFMA, fp32 accumulate.  W_bf16 holds the (N,K) weight zero-padded to (Npad32, Kpad16) in MFMA B-fragment order
+ * (diffalign_amd/pack.py bf16_weight): 1 KiB fragments [nt][ks], lane (r,h) element j = W[32nt + r][16ks + 8h + j]; K <= 256. */
 int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float* bias, const uint8_t* rowmask, float* out,
               int ldc, int M, int N, int K, int relu, void* stream);
 
