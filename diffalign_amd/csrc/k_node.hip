@@ -11,42 +11,77 @@
 // lane (r,h) element j = W[32nt + r][16ks + 8h + j]; fragments are stored [nt][ks], 1 KiB each, so a wave's operand
 // read is one coalesced 1 KiB line set.  KSMAX*16 >= Kpad: the wave's 32 activation rows are converted to bf16
 // A fragments once and stay in registers while it walks its NTILE output tiles.
-template <int NTILE, int KSMAX, bool RELU>
-__global__ void __launch_bounds__(256) k_linear(const float* __restrict__ A, int lda, const uint4* __restrict__ W, int KS,
-                                                const float* __restrict__ bias, const uint8_t* __restrict__ rowmask,
-                                                float* __restrict__ out, int ldc, int M, int N, int K) {
+// The loops run KSMAX k-steps without branches (steps >= KS multiply a zero activation fragment by a clamped, valid
+// weight fragment): with a branch per step every load waits for the previous one (no hoisting across basic blocks).
+// VEC: rows are 16-byte aligned and K is a multiple of 8 (float4 loads); otherwise guarded scalar loads.
+// One wave owns 32 rows and walks `ntiles` 32-column output tiles (blockIdx.y selects the column group); the weight
+// fragments of the next tile are fetched while the current tile's MFMAs and stores run (two register buffers).
+template <int KSMAX, bool RELU, bool VEC>
+__global__ void __launch_bounds__(256, 2) k_linear(const float* __restrict__ A, int lda, const uint4* __restrict__ W, int KS,
+                                                   const float* __restrict__ bias, const uint8_t* __restrict__ rowmask,
+                                                   float* __restrict__ out, int ldc, int M, int N, int K, int ntiles) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = (blockIdx.x * 4 + wave) * 32;
-  const int nt0 = blockIdx.y * NTILE;
+  const int nt0 = blockIdx.y * ntiles;
   if (m0 >= M) return;
   const int arow = min(m0 + r, M - 1);
   const float* ap = A + (size_t)arow * lda;
-  const bool vec_ok = ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
   bf16x8 af[KSMAX];
+  if (VEC) {
 #pragma unroll
-  for (int s = 0; s < KSMAX; ++s) {
-    if (s < KS) {
+    for (int s0 = 0; s0 < KSMAX; s0 += 8) {            // eight k-steps (16 float4) in flight at a time
+      float4 x0[8], x1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < KSMAX) {
+          const int kb = 16 * min(s0 + u, KS - 1) + 8 * h;
+#ifdef EXP_LIN_NOA
+          x0[u] = float4{(float)kb, 1.f, 2.f, (float)lane}; x1[u] = x0[u];
+#else
+          x0[u] = *reinterpret_cast<const float4*>(ap + kb);
+          x1[u] = *reinterpret_cast<const float4*>(ap + kb + 4);
+#endif
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < KSMAX) {
+          const bool on = s0 + u < KS;
+          const uint4 au = {pack_bf16(x0[u].x, x0[u].y), pack_bf16(x0[u].z, x0[u].w), pack_bf16(x1[u].x, x1[u].y), pack_bf16(x1[u].z, x1[u].w)};
+          const uint4 z = {0u, 0u, 0u, 0u};
+          af[s0 + u] = frag_from_u4(on ? au : z);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KSMAX; ++s) {
       const int kb = 16 * s + 8 * h;
       float av[8];
-      if (vec_ok && kb + 8 <= K) {
-        const float4 x0 = *reinterpret_cast<const float4*>(ap + kb), x1 = *reinterpret_cast<const float4*>(ap + kb + 4);
-        av[0] = x0.x; av[1] = x0.y; av[2] = x0.z; av[3] = x0.w; av[4] = x1.x; av[5] = x1.y; av[6] = x1.z; av[7] = x1.w;
-      } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
-      }
+      for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
       const uint4 au = {pack_bf16(av[0], av[1]), pack_bf16(av[2], av[3]), pack_bf16(av[4], av[5]), pack_bf16(av[6], av[7])};
       af[s] = frag_from_u4(au);
     }
   }
+  uint8_t rm[16];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
-    const uint4* wp = W + ((size_t)(nt0 + t) * KS) * 64 + lane;
+  for (int i = 0; i < 16; ++i) rm[i] = rowmask ? rowmask[min(m0 + crow(i, h), M - 1)] : (uint8_t)1;
+  const int NTall = (N + 31) / 32;
+  auto load_w = [&](uint4 (&wf)[KSMAX], int t) {
+    const uint4* wp = W + ((size_t)min(nt0 + t, NTall - 1) * KS) * 64 + lane;
+#pragma unroll
+#ifdef EXP_LIN_NOW
+    for (int s = 0; s < KSMAX; ++s) wf[s] = uint4{(unsigned)t, (unsigned)s, 0x3f803f80u, (unsigned)lane};
+#else
+    for (int s = 0; s < KSMAX; ++s) wf[s] = wp[min(s, KS - 1) * 64];
+#endif
+  };
+  auto tile = [&](const uint4 (&wf)[KSMAX], int t) {
     f32x16 acc = splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < KSMAX; ++s)
-      if (s < KS) acc = mfma32(af[s], frag_from_u4(wp[s * 64]), acc);
+    for (int s = 0; s < KSMAX; ++s) acc = mfma32(af[s], frag_from_u4(wf[s]), acc);
     const int col = (nt0 + t) * 32 + r;
     if (col < N) {
       const float bv = bias ? bias[col] : 0.f;
@@ -56,10 +91,22 @@ __global__ void __launch_bounds__(256) k_linear(const float* __restrict__ A, int
         if (row >= M) continue;
         float v = acc[i] + bv;
         if (RELU) v = fmaxf(v, 0.f);
-        if (rowmask) v = rowmask[row] ? v : 0.f;
+        v = rm[i] ? v : 0.f;
+#ifdef EXP_LIN_NOSTORE
+        if (v == 1234.5678f) out[(size_t)row * ldc + col] = v;
+#else
         out[(size_t)row * ldc + col] = v;
+#endif
       }
     }
+  };
+  uint4 wA[KSMAX], wB[KSMAX];
+  load_w(wA, 0);
+  for (int t = 0; t < ntiles; t += 2) {
+    load_w(wB, t + 1);
+    tile(wA, t);
+    load_w(wA, t + 2);
+    if (t + 1 < ntiles) tile(wB, t + 1);
   }
 }
 
@@ -327,20 +374,28 @@ int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float
   const int gm = (M + 127) / 128;
   const int KS = Kpad / 16;
   const uint4* Wf = (const uint4*)W;
-#define DA_LIN(NTILE_, KSMAX_)                                                                                             \
+  const bool vec = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);   // with K == Kpad: float4 loads of whole k-steps
+  // column groups: enough waves to fill the chip (about one per SIMD) without re-reading the activations more than needed
+  const int NTall = Npad / 32;
+  const long long rowtiles = (M + 31) / 32;
+  int groups = 1;
+  while (groups < NTall && rowtiles * groups < 1024 && NTall % (groups * 2) == 0) groups *= 2;
+  const int ntiles = NTall / groups;
+#define DA_LIN2(KSMAX_, RELU_, VEC_)                                                                                       \
+  k_linear<KSMAX_, RELU_, VEC_><<<dim3(gm, groups), 256, 0, s>>>(A, lda, Wf, KS, bias, rowmask, out, ldc, M, N, K, ntiles)
+#define DA_LIN(KSMAX_)                                                                                                     \
   do {                                                                                                                     \
-    dim3 grid(gm, Npad / (32 * NTILE_));                                                                                   \
-    if (relu) k_linear<NTILE_, KSMAX_, true><<<grid, 256, 0, s>>>(A, lda, Wf, KS, bias, rowmask, out, ldc, M, N, K);       \
-    else k_linear<NTILE_, KSMAX_, false><<<grid, 256, 0, s>>>(A, lda, Wf, KS, bias, rowmask, out, ldc, M, N, K);          \
+    if (vec && K == Kpad) { if (relu) DA_LIN2(KSMAX_, true, true); else DA_LIN2(KSMAX_, false, true); }                    \
+    else { if (relu) DA_LIN2(KSMAX_, true, false); else DA_LIN2(KSMAX_, false, false); }                                   \
   } while (0)
-  if (KS <= 4) {
-    if (Npad % 128 == 0) DA_LIN(4, 4); else if (Npad % 64 == 0) DA_LIN(2, 4); else DA_LIN(1, 4);
-  } else if (KS <= 16) {
-    if (Npad % 128 == 0) DA_LIN(4, 16); else if (Npad % 64 == 0) DA_LIN(2, 16); else DA_LIN(1, 16);
-  } else {
+  if (KS <= 4) DA_LIN(4);
+  else if (KS <= 16) DA_LIN(16);
+  else {
     da_set_error("da_linear: K=%d not built (K <= 256)", K);
     return DA_ERR_UNSUPPORTED;
   }
+#undef DA_LIN
+#undef DA_LIN2
 #undef DA_LIN
   DA_CHECK_LAUNCH("da_linear");
   return DA_OK;

@@ -62,6 +62,8 @@ class PackedModel:
         self.skip = None
         if prefix + 'skip_scaling' in sd:
             self.skip = (f32(g('skip_scaling')), f32(g('skip_scaling_2')))
+        lib.da_x_post_blob_bytes.restype = C.c_longlong
+        self.fused_x = lib.da_x_post_blob_bytes(_i(self.dx), _i(self.dffx)) > 0     # else: the unfused da_linear chain
         self.layers = []
         for l in range(n_layers):
             p = f'tf_layers.{l}'
@@ -83,6 +85,8 @@ class PackedModel:
                 W1=bw(p + '.linX1.weight'), b1=f32(g(p + '.linX1.bias')), W2=bw(p + '.linX2.weight'), b2=f32(g(p + '.linX2.bias')),
                 n1=(f32(g(p + '.normX1.weight')), f32(g(p + '.normX1.bias'))),
                 n2=(f32(g(p + '.normX2.weight')), f32(g(p + '.normX2.bias'))),
+                xpost=(pack.x_post_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev)
+                       if self.fused_x else None),
                 film=_PtrArray(film), yup=_PtrArray(yup)))
 
 
@@ -126,18 +130,22 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
             'da_edge_layer')
     if PROFILE_EVENTS is not None:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
-    newX = torch.empty(R, dx, device=dev)
-    _linear(newX_in, dx, lw['Wxo'], lw['bxo'], nm_u8, newX, dx, R, dx, dx, False)
-    X1 = torch.empty(R, dx, device=dev)
-    L.check(lib.da_add_layernorm(L.ptr(X), L.ptr(newX), L.ptr(lw['n1'][0]), L.ptr(lw['n1'][1]), L.ptr(X1), _i(R), _i(dx), S),
-            'da_add_layernorm')
-    hbuf = torch.empty(R, pm.dffx, device=dev)
-    _linear(X1, dx, lw['W1'], lw['b1'], None, hbuf, pm.dffx, R, pm.dffx, dx, True)
-    ff = newX
-    _linear(hbuf, pm.dffx, lw['W2'], lw['b2'], None, ff, dx, R, dx, pm.dffx, False)
     X2 = torch.empty(B, n, dx, device=dev)
-    L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
-            'da_add_layernorm')
+    if lw['xpost'] is not None:
+        L.check(lib.da_x_post(L.ptr(newX_in), L.ptr(X), L.ptr(nm_u8), L.ptr(lw['xpost']), L.ptr(X2), _i(R), _i(dx), _i(pm.dffx), S),
+                'da_x_post')
+    else:
+        newX = torch.empty(R, dx, device=dev)
+        _linear(newX_in, dx, lw['Wxo'], lw['bxo'], nm_u8, newX, dx, R, dx, dx, False)
+        X1 = torch.empty(R, dx, device=dev)
+        L.check(lib.da_add_layernorm(L.ptr(X), L.ptr(newX), L.ptr(lw['n1'][0]), L.ptr(lw['n1'][1]), L.ptr(X1), _i(R), _i(dx), S),
+                'da_add_layernorm')
+        hbuf = torch.empty(R, pm.dffx, device=dev)
+        _linear(X1, dx, lw['W1'], lw['b1'], None, hbuf, pm.dffx, R, pm.dffx, dx, True)
+        ff = newX
+        _linear(hbuf, pm.dffx, lw['W2'], lw['b2'], None, ff, dx, R, dx, pm.dffx, False)
+        L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
+                'da_add_layernorm')
     y2 = torch.empty(B, dy, device=dev)
     xst = torch.empty(B, N_XSTAT_CHUNKS, 4, dx, device=dev)
     L.check(lib.da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(dx), _i(N_XSTAT_CHUNKS), S), 'da_x_stats')

@@ -76,6 +76,19 @@ def edge_layer_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
     return _blob(frags, params)
 
 
+def x_post_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    """Blob for da_x_post; p = 'tf_layers.{l}' key prefix.  Layout = XPostCfg in csrc/k_x_post.hip."""
+    g = lambda k: sd[p + k].detach().float().cpu()
+    Wxo, W1, W2 = g('.self_attn.x_out.weight'), g('.linX1.weight'), g('.linX2.weight')
+    dx, dff = Wxo.shape[0], W1.shape[0]
+    frags = [_frag(Wxo, mt, s, False) for mt in range(dx // 32) for s in range(dx // 16)]
+    frags += [_frag(W1, ht, s, True) for ht in range(dff // 32) for s in range(dx // 16)]
+    frags += [_frag(W2, mt, s, True) for mt in range(dx // 32) for s in range(dff // 16)]
+    params = [g('.self_attn.x_out.bias'), g('.normX1.weight'), g('.normX1.bias'), g('.linX1.bias'), g('.linX2.bias'),
+              g('.normX2.weight'), g('.normX2.bias')]
+    return _blob(frags, params)
+
+
 def edge_in_blob(sd, prefix='') -> torch.Tensor:
     g = lambda k: sd[prefix + k].detach().float().cpu()
     W0, W1 = g('mlp_in_E.0.weight'), g('mlp_in_E.2.weight')

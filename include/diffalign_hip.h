@@ -85,6 +85,7 @@ long long da_edge_blob_bytes(int de, int dx, int dff);      /* -1 when the shape
 long long da_edge_in_blob_bytes(int de, int he);
 long long da_edge_out_blob_bytes(int de, int he);
 long long da_kv_frag_bytes(int B, int n, int dx);
+long long da_x_post_blob_bytes(int dx, int dffx);           /* -1 when the shape is not built */
 
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask): every nn.Linear of the node path -- mlp_in_X / mlp_out_X
  * (transformer_model_with_y.py:584-585,602-603), q/k/v/x_out (layers.py:217-218,256,273), linX1/linX2 (layers.py:349).
@@ -92,6 +93,12 @@ long long da_kv_frag_bytes(int B, int n, int dx);
  * (diffalign_amd/pack.py bf16_weight): 1 KiB fragments [nt][ks], lane (r,h) element j = W[32nt + r][16ks + 8h + j]; K <= 256. */
 int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float* bias, const uint8_t* rowmask, float* out,
               int ldc, int M, int N, int K, int relu, void* stream);
+
+/* Node side of one XEyTransformerLayer after the attention, fused: newX = x_out(newX_in) * mask (layers.py:268-273);
+ * X1 = normX1(X + newX); X' = normX2(X1 + linX2(relu(linX1(X1)))) (layers.py:343-351).  fp32 (rows, dx) row-major in/out,
+ * blob = diffalign_amd/pack.py x_post_blob (XPostCfg layout).  Built: (dx, dim_ffX) = (256,256), (64,64). */
+int da_x_post(const float* newX_in, const float* X, const uint8_t* node_mask, const void* blob, float* X_out, int rows, int dx,
+              int dffx, void* stream);
 
 /* out = LayerNorm(a + b) * gamma + beta, eps 1e-5: normX1 / normX2 (layers.py:341,351). b may be NULL. */
 int da_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* out, int rows, int D,

@@ -155,3 +155,33 @@ def test_missing_dims_fail_loudly():
     with pytest.raises(L.DiffAlignHipError):
         with torch.no_grad():
             m(X.to(D), E.to(D), y.to(D), nm.to(D), am.to(D), pos.to(D), mol.to(D))
+
+
+@pytest.mark.parametrize('dims', [FULL, TINY], ids=['full', 'tiny'])
+def test_x_post_vs_torch(dims):
+    """da_x_post (x_out + mask, normX1, FFN, normX2 fused) against the same chain in fp32 torch; rows not a tile multiple."""
+    from diffalign_amd import pack, _lib as L
+    import ctypes as C
+    dx, dff = dims['hidden_dims']['dx'], dims['hidden_dims']['dim_ffX']
+    g = torch.Generator().manual_seed(5)
+    R = 3 * 41 + 7
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    sd = {'p.self_attn.x_out.weight': rnd(dx, dx) / math.sqrt(dx), 'p.self_attn.x_out.bias': rnd(dx) * 0.1,
+          'p.linX1.weight': rnd(dff, dx) / math.sqrt(dx), 'p.linX1.bias': rnd(dff) * 0.1,
+          'p.linX2.weight': rnd(dx, dff) / math.sqrt(dff), 'p.linX2.bias': rnd(dx) * 0.1,
+          'p.normX1.weight': 1 + 0.1 * rnd(dx), 'p.normX1.bias': 0.1 * rnd(dx),
+          'p.normX2.weight': 1 + 0.1 * rnd(dx), 'p.normX2.bias': 0.1 * rnd(dx)}
+    newX_in, X = rnd(R, dx), rnd(R, dx)
+    mask = torch.rand(R, generator=g) > 0.2
+    newX = F.linear(newX_in, sd['p.self_attn.x_out.weight'], sd['p.self_attn.x_out.bias']) * mask[:, None]
+    X1 = F.layer_norm(X + newX, (dx,), sd['p.normX1.weight'], sd['p.normX1.bias'], 1e-5)
+    ff = F.linear(F.relu(F.linear(X1, sd['p.linX1.weight'], sd['p.linX1.bias'])), sd['p.linX2.weight'], sd['p.linX2.bias'])
+    ref = F.layer_norm(X1 + ff, (dx,), sd['p.normX2.weight'], sd['p.normX2.bias'], 1e-5)
+    blob = pack.x_post_blob(sd, 'p').to(D)
+    out = torch.full((R, dx), float('nan'), device=D)
+    a, b, m = newX_in.to(D), X.to(D), L.as_u8(mask.to(D))
+    L.check(L.lib().da_x_post(L.ptr(a), L.ptr(b), L.ptr(m), L.ptr(blob), L.ptr(out), C.c_int(R), C.c_int(dx), C.c_int(dff),
+                              L.stream()), 'da_x_post')
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2
