@@ -217,19 +217,21 @@ __device__ __forceinline__ void block_matvec_T(const float* __restrict__ WT, con
   // requires blockDim.x % O == 0
   const int slices = blockDim.x / O, o = threadIdx.x % O, sl = threadIdx.x / O;
   const int per = (K + slices - 1) / slices, k0 = sl * per, k1 = min(K, k0 + per);
-  float acc[8];
+  float acc[16];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
   int k = k0;
-  for (; k + 8 <= k1; k += 8) {
-    float w[8];
+  for (; k + 16 <= k1; k += 16) {
+    float w[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = WT[(size_t)(k + u) * O + o];      // 8 independent loads in flight
+    for (int u = 0; u < 16; ++u) w[u] = WT[(size_t)(k + u) * O + o];     // 16 independent loads in flight
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = fmaf(w[u], v[k + u], acc[u]);
+    for (int u = 0; u < 16; ++u) acc[u] = fmaf(w[u], v[k + u], acc[u]);
   }
   for (; k < k1; ++k) acc[0] = fmaf(WT[(size_t)k * O + o], v[k], acc[0]);
-  const float s0 = (acc[0] + acc[1]) + (acc[2] + acc[3]), s1 = (acc[4] + acc[5]) + (acc[6] + acc[7]);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { s0 += acc[u]; s1 += acc[8 + u]; }
   scratch[threadIdx.x] = s0 + s1;
   __syncthreads();
   if (threadIdx.x < O) {
@@ -311,7 +313,7 @@ __device__ __forceinline__ void pooled_stats(const float* part, int nchunk, int 
 }
 // new_y = y_out(y + Xtoy(X) + Etoy(E)); y = LN(y+new_y); y = LN(y + lin_y2(relu(lin_y1(y))))
 // (layers.py:15-47,277-281,346-359).  Statistics run over ALL n nodes / n^2 pairs (padding included), std unbiased.
-__global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
+__global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
   extern __shared__ float sm[];
   float* sx = sm;                       // 4*dx
   float* se = sx + 4 * a.dx;            // 4*de
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(256) k_y_update(YUpdArgs a) {
   float* v1 = v0 + a.dy;                // dy
   float* v2 = v1 + a.dy;                // dy
   float* hb = v2 + a.dy;                // dff
-  float* scr = hb + a.dff;              // 256
+  float* scr = hb + a.dff;              // blockDim.x
   const int b = blockIdx.x, n = a.n;
   pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx);
   pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se);
@@ -462,12 +464,12 @@ int da_x_stats(const float* X, float* partials, int B, int n, int D, int nchunk,
 int da_y_update(const float* y, const float* xstats, const float* estats,
                 const float* const* w /* 16 pointers, YUpdArgs order */, float* out, int B, int n, int dx, int de, int dy,
                 int dff, int nchunk_x, int nchunk_e, void* stream) {
-  DA_CHECK_ARG(dy > 0 && 256 % dy == 0, "da_y_update: dy=%d must divide 256", dy);
+  DA_CHECK_ARG(dy > 0 && 1024 % dy == 0, "da_y_update: dy=%d must divide 1024", dy);
   if (B == 0) return DA_OK;
   YUpdArgs a{y, xstats, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
              w[14], w[15], out, n, dx, de, dy, dff, nchunk_x, nchunk_e};
-  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 256) * sizeof(float);
-  k_y_update<<<B, 256, sh, (hipStream_t)stream>>>(a);
+  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 1024) * sizeof(float);
+  k_y_update<<<B, 1024, sh, (hipStream_t)stream>>>(a);
   DA_CHECK_LAUNCH("da_y_update");
   return DA_OK;
 }
