@@ -270,7 +270,7 @@ struct YFilmArgs {
   const float* y;                                     // (B,dy)
   const float *We_add, *be_add, *We_mul, *be_mul;     // y_e_add / y_e_mul  (dx,dy)
   const float *Wx_add, *bx_add, *Wx_mul, *bx_mul;     // y_x_add / y_x_mul  (dx,dy)
-  const float *Wout, *bout;                           // e_out (de,dx)
+  const float *Wout, *bout;                           // e_out.weight TRANSPOSED (dx,de), e_out.bias
   float *ye2p1, *ebias, *yx1, *yx2p1;
   int dy, dx, de;
 };
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
   block_matvec(a.Wx_add, a.dy, a.bx_add, v, a.yx1 + (size_t)b * a.dx, a.dx, a.dy, false);
   block_matvec(a.Wx_mul, a.dy, a.bx_mul, v, a.yx2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
   __syncthreads();
-  block_matvec(a.Wout, a.dx, a.bout, ye1, a.ebias + (size_t)b * a.de, a.de, a.dx, false);
+  block_matvec_T(a.Wout, a.bout, ye1, a.ebias + (size_t)b * a.de, ye1 + a.dx, a.de, a.dx, false);   // Wout = e_out.weight^T (dx,de)
 }
 
 struct YUpdArgs {
@@ -298,18 +298,32 @@ struct YUpdArgs {
   float* out;
   int n, dx, de, dy, dff, nchunk_x, nchunk_e;
 };
-__device__ __forceinline__ void pooled_stats(const float* part, int nchunk, int d, double N, float* dst) {
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
-    for (int k = 0; k < nchunk; ++k) {
+// chunk partials -> (mean, min, max, unbiased std) per channel in dst[4*d].  Threads = (channel, chunk slice): every slice
+// folds its chunks with independent loads, the slices meet in LDS `scr` (>= 4 * blockDim.x floats).  Ends synchronised.
+__device__ __forceinline__ void pooled_stats(const float* part, int nchunk, int d, double N, float* dst, float* scr) {
+  const int slices = max(1, (int)blockDim.x / d), c = threadIdx.x % d, sl = threadIdx.x / d;
+  float s = 0.f, q = 0.f, mn = INFINITY, mx = -INFINITY;
+  if (sl < slices) {
+#pragma unroll 4
+    for (int k = sl; k < nchunk; k += slices) {
       const float* p = part + (size_t)k * 4 * d;
       s += p[c]; q += p[d + c]; mn = fminf(mn, p[2 * d + c]); mx = fmaxf(mx, p[3 * d + c]);
     }
-    const double mean = s / N;
-    double var = N > 1 ? (q - N * mean * mean) / (N - 1) : 0.0;
-    if (var < 0) var = 0;
-    dst[c] = (float)mean; dst[d + c] = mn; dst[2 * d + c] = mx; dst[3 * d + c] = (float)sqrt(var);
   }
+  scr[threadIdx.x] = s; scr[blockDim.x + threadIdx.x] = q; scr[2 * blockDim.x + threadIdx.x] = mn; scr[3 * blockDim.x + threadIdx.x] = mx;
+  __syncthreads();
+  if (threadIdx.x < d) {
+    double S = 0.0, Q = 0.0; float MN = INFINITY, MX = -INFINITY;
+    for (int u = 0; u < slices; ++u) {
+      const int t = u * d + c;
+      S += scr[t]; Q += scr[blockDim.x + t]; MN = fminf(MN, scr[2 * blockDim.x + t]); MX = fmaxf(MX, scr[3 * blockDim.x + t]);
+    }
+    const double mean = S / N;
+    double var = N > 1 ? (Q - N * mean * mean) / (N - 1) : 0.0;
+    if (var < 0) var = 0;
+    dst[c] = (float)mean; dst[d + c] = MN; dst[2 * d + c] = MX; dst[3 * d + c] = (float)sqrt(var);
+  }
+  __syncthreads();
 }
 // new_y = y_out(y + Xtoy(X) + Etoy(E)); y = LN(y+new_y); y = LN(y + lin_y2(relu(lin_y1(y))))
 // (layers.py:15-47,277-281,346-359).  Statistics run over ALL n nodes / n^2 pairs (padding included), std unbiased.
@@ -321,10 +335,10 @@ __global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
   float* v1 = v0 + a.dy;                // dy
   float* v2 = v1 + a.dy;                // dy
   float* hb = v2 + a.dy;                // dff
-  float* scr = hb + a.dff;              // blockDim.x
+  float* scr = hb + a.dff;              // 4 * blockDim.x
   const int b = blockIdx.x, n = a.n;
-  pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx);
-  pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se);
+  pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx, scr);
+  pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se, scr);
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v0[k] = a.y[(size_t)b * a.dy + k];
   __syncthreads();
   block_matvec_T(a.WxyT, a.bxy, sx, v1, scr, a.dy, 4 * a.dx, false);
@@ -448,7 +462,8 @@ int da_y_film(const float* y, const float* const* w /* 10 pointers, YFilmArgs or
               float* yx1, float* yx2p1, int B, int dy, int dx, int de, void* stream) {
   if (B == 0) return DA_OK;
   YFilmArgs a{y, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], ye2p1, ebias, yx1, yx2p1, dy, dx, de};
-  k_y_film<<<B, 256, (dy + dx) * sizeof(float), (hipStream_t)stream>>>(a);
+  DA_CHECK_ARG(de > 0 && 256 % de == 0, "da_y_film: de=%d must divide 256", de);
+  k_y_film<<<B, 256, (dy + dx + 256) * sizeof(float), (hipStream_t)stream>>>(a);
   DA_CHECK_LAUNCH("da_y_film");
   return DA_OK;
 }
@@ -468,7 +483,7 @@ int da_y_update(const float* y, const float* xstats, const float* estats,
   if (B == 0) return DA_OK;
   YUpdArgs a{y, xstats, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
              w[14], w[15], out, n, dx, de, dy, dff, nchunk_x, nchunk_e};
-  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 1024) * sizeof(float);
+  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 4 * 1024) * sizeof(float);
   k_y_update<<<B, 1024, sh, (hipStream_t)stream>>>(a);
   DA_CHECK_LAUNCH("da_y_update");
   return DA_OK;

@@ -70,10 +70,10 @@ class PackedModel:
             a = p + '.self_attn'
             Wqkv = torch.cat([g(a + '.q.weight'), g(a + '.k.weight'), g(a + '.v.weight')], 0)
             bqkv = torch.cat([g(a + '.q.bias'), g(a + '.k.bias'), g(a + '.v.bias')], 0)
-            film = [f32(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
-                                            '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias',
-                                            '.e_out.weight', '.e_out.bias')]
             tr = lambda t: t.detach().float().t().contiguous().to(dev)      # transposed [K][O] for block_matvec_T
+            film = [f32(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
+                                            '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias')]
+            film += [tr(g(a + '.e_out.weight')), f32(g(a + '.e_out.bias'))]
             yup = [tr(g(a + '.x_y.lin.weight')), f32(g(a + '.x_y.lin.bias')), tr(g(a + '.e_y.lin.weight')), f32(g(a + '.e_y.lin.bias')),
                    f32(g(a + '.y_out.0.weight')), f32(g(a + '.y_out.0.bias')), f32(g(a + '.y_out.2.weight')), f32(g(a + '.y_out.2.bias')),
                    f32(g(p + '.norm_y1.weight')), f32(g(p + '.norm_y1.bias')), f32(g(p + '.lin_y1.weight')), f32(g(p + '.lin_y1.bias')),

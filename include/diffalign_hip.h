@@ -118,7 +118,7 @@ int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, c
 
 /* Per-layer FiLM vectors from y (layers.py:245-247,268-270): ye2p1 = 1+y_e_mul(y), ebias = e_out.b + e_out.W y_e_add(y),
  * yx1 = y_x_add(y), yx2p1 = 1+y_x_mul(y).  w = host array of 10 device pointers: y_e_add.{W,b}, y_e_mul.{W,b},
- * y_x_add.{W,b}, y_x_mul.{W,b}, e_out.{W,b}. */
+ * y_x_add.{W,b}, y_x_mul.{W,b}, e_out.{W TRANSPOSED (dx,de), b}. */
 int da_y_film(const float* y, const float* const* w /*host*/, float* ye2p1, float* ebias, float* yx1, float* yx2p1, int B,
               int dy, int dx, int de, void* stream);
 
