@@ -72,15 +72,29 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
     const bool mi = nm[row] != 0;
     for (int jt = 0; jt < NT; ++jt) {
       const int jl = jt * 32 + r; const bool jvalid = jl < n; const int jc = jvalid ? jl : n - 1;
-      f32x16 o[C::MT], om[C::MT];
-      mlp_in_chain<DE, HE>(E_in + ((size_t)row * n + jc) * de_in, de_in, h, lane, sW0, sW1, sP, o);
-      mlp_in_chain<DE, HE>(E_in + (((size_t)b * n + jc) * n + i) * de_in, de_in, h, lane, sW0, sW1, sP, om);
+      f32x16 o[C::MT];
+      const float* pij = E_in + ((size_t)row * n + jc) * de_in;
+      const float* pji = E_in + (((size_t)b * n + jc) * n + i) * de_in;
+      // symmetric input tile (the diffusion state always is): mlp(E_ij) == mlp(E_ji) bit for bit, one evaluation is enough
+      bool same = true;
+      for (int c = 8 * h; c < min(de_in, 8 * h + 8); ++c) same = same && (pij[c] == pji[c]);
+      const bool sym_tile = __all(same);               // wave-uniform
+      mlp_in_chain<DE, HE>(pij, de_in, h, lane, sW0, sW1, sP, o);
       const float pm = (mi && jvalid && nm[b * n + jc] && jc != i) ? 1.f : 0.f;
       float sum = 0.f;
+      if (sym_tile) {
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) { const float v = (o[mt][i2] + om[mt][i2]) * 0.5f * pm; o[mt][i2] = v; sum += v; }
+          for (int i2 = 0; i2 < 16; ++i2) { const float v = (o[mt][i2] + o[mt][i2]) * 0.5f * pm; o[mt][i2] = v; sum += v; }
+      } else {
+        f32x16 om[C::MT];
+        mlp_in_chain<DE, HE>(pji, de_in, h, lane, sW0, sW1, sP, om);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int i2 = 0; i2 < 16; ++i2) { const float v = (o[mt][i2] + om[mt][i2]) * 0.5f * pm; o[mt][i2] = v; sum += v; }
+      }
       sum = xhalf_sum(sum);
       if (sum == 0.f && h == 0) o[0][0] = 1.f;        // encode_no_element on the hidden features
 #pragma unroll

@@ -74,6 +74,18 @@ def test_stages_vs_oracle(dims):
     _, ref = O.mask_dense(torch.zeros(B, n, 1), ref, nm)
     assert rel_l2(Eh.float(), ref) <= 1e-2
     assert torch.equal(Eh.float().cpu()[~(nm[:, :, None] & nm[:, None, :])][:, 0], torch.ones(int((~(nm[:, :, None] & nm[:, None, :])).sum())))
+    # -- input stage on a NON-symmetric edge tensor (the mirrored evaluation is skipped only on symmetric tiles)
+    Ea = torch.rand(B, n, n, KE, generator=torch.Generator().manual_seed(17))
+    Ea_d = Ea.to(D)
+    Eh2 = torch.empty_like(Eh)
+    L.check(L.lib().da_edge_in(L.ptr(Ea_d), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(Eh2), engine._i(B),
+                               engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in')
+    ref = F.relu(F.linear(F.relu(F.linear(Ea, sd['mlp_in_E.0.weight'], sd['mlp_in_E.0.bias'])), sd['mlp_in_E.2.weight'],
+                          sd['mlp_in_E.2.bias']))
+    ref = (ref + ref.transpose(1, 2)) / 2
+    _, ref = O.mask_dense(torch.zeros(B, n, 1), ref, nm)
+    assert rel_l2(Eh2.float(), ref) <= 1e-2
+    assert torch.equal(Eh2, Eh2.transpose(1, 2))
     # -- one layer on random hidden features
     g = torch.Generator().manual_seed(3)
     Xh = torch.randn(B, n, hd['dx'], generator=g); yh = torch.randn(B, hd['dy'], generator=g)
