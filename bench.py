@@ -51,21 +51,22 @@ def make_info():
 
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement of the reference, oracle/oracle.py) timed on this host: same network, same step,
-    a bounded sample of the workload (B=2 graphs, n=96 nodes, one reverse step)."""
+    a bounded sample of the same workload (graphs of the benchmark's own size n=300, P=144, one at a time, for about
+    `seconds_budget` seconds of CPU work)."""
     from oracle import oracle as O
     from diffalign_amd import synthetic as S
     from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
     import torch.nn as nn
     cores = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
     torch.set_num_threads(cores)
-    B, n = 2, 96
+    B, n = 1, 300
     torch.manual_seed(0)
     KX, KE = len(S.ATOM_DECODER), len(S.BOND_DECODER)
     m = GraphTransformerWithYAtomMapPosEmb(9, {'X': KX + 8, 'E': KE, 'y': 13}, FULL['hidden_mlp_dims'], FULL['hidden_dims'],
                                            {'X': KX, 'E': KE, 'y': 1}, nn.ReLU(), nn.ReLU(), p_to_r_skip_connection=True,
                                            p_to_r_init=1.0, alignment_type='correct')
     sd = {k: v.detach() for k, v in m.state_dict().items()}
-    true = S.make_reaction_batch(B, n, seed=1, P=40)
+    true = S.make_reaction_batch(B, n, seed=1, P=(n - S.NB_DUMMY - 1) // 2)
     zt = S.noised_state(true, t=50, T=100, abs_x=S.IDX_AU, seed=2)
     g = torch.Generator().manual_seed(3)
     X = torch.cat([zt['X'], torch.rand(B, n, 8, generator=g)], -1)
@@ -81,12 +82,12 @@ def cpu_baseline(seconds_budget=25.0):
                                            zt['mol_assignments'], True)
             O.reverse_step(lX, lE, zt['X'], zt['E'], zt['node_mask'], tabs, 50, true['X'], true['E'], mx, me, qX, qE)
             steps += 1
-            if time.time() - t0 > seconds_budget * 0.5 or steps >= 8:
+            if time.time() - t0 > seconds_budget * 0.6 or steps >= 64:
                 break
     dt = time.time() - t0
     return {'value': B * steps / dt, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/oracle.py (fp32 torch CPU), full align_absorbing dims, {steps} reverse step(s) of B={B} graphs at n={n} '
-                      f'in {dt:.1f}s; per-graph cost grows ~n^2, the GPU workload is n=300'}
+            'sample': f'oracle/oracle.py (fp32 torch CPU, {cores} threads), full align_absorbing dims, {steps} reverse step(s) of '
+                      f'B={B} graph at n={n} (the graph size of the GPU workload) in {dt:.1f}s'}
 
 
 def main():
@@ -189,8 +190,19 @@ def main():
     t_s = edge_ms * 1e-3
     tf = flops_launch / t_s / 1e12 if t_s > 0 else 0.0
     gbs = bytes_launch / t_s / 1e9 if t_s > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per the gfx950 note in
+    # MI355X_MICROARCH.md), valid for the workload they were taken on only
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'edge_layer_traffic.json')) as f:
+            tj = json.load(f)
+        if tj['workload'] == {'B': B, 'n': n}:
+            traffic = tj['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
+            'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
+            'algorithmic_bytes_per_launch': bytes_launch, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
     if rank == 0:
         out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',
