@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, 'libdiffalign_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
 # the diffusion kernels keep the CPU oracle's arithmetic order (no fma contraction): probabilities match to 2e-6
-EXTRA = {'k_diffusion.hip': ['-ffp-contract=off']}
+EXTRA = {'k_diffusion.hip': ['-ffp-contract=off'], 'k_elbo.hip': ['-ffp-contract=off']}
 
 
 def _stale(src, obj, deps):

@@ -9,11 +9,12 @@ import torch.nn as nn
 from . import graph, helpers
 from .noise_schedule import (AbsorbingStateTransitionMaskNoEdge, DiscreteUniformTransition, MarginalUniformTransition)
 from .placeholder import PlaceHolder
+from .elbo import ELBOMixin
 from .sampling import SamplingMixin
 from .transformer_model_with_y import GraphTransformerWithY, GraphTransformerWithYAtomMapPosEmb
 
 
-class DiscreteDenoisingDiffusion(SamplingMixin, nn.Module):
+class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
     def __init__(self, cfg, dataset_infos, node_type_counts_unnormalized=None, edge_type_counts_unnormalized=None,
                  use_data_parallel=None, device='cuda:0'):
         super().__init__()

@@ -73,6 +73,27 @@ int da_sample_discrete(const float* prob_X, const float* prob_E, const uint8_t* 
 int da_noise_probs(const float* X, const float* E, const uint8_t* node_mask, const float* Qtb_x, const float* Qtb_e,
                    float* prob_X, float* prob_E, int B, int n, int kx, int ke, void* stream);
 
+/* ---- ELBO / CE terms ----------------------------------------------------------------------------------------------
+ * Per-node (B,n) and per-ordered-pair (B,n,n) rows of one term of the objective; true / zt one-hot fp32, logits fp32.
+ *  mode 0  L_t, probability space: KL(q(z_s|z_t,x_0) || p(z_s|z_t)), both apply_mask-ed, eps inside the log
+ *          (diffalign/diffusion/elbo.py:85-162 with log=False; helpers.py:754-771)
+ *  mode 1  L_t, log space (training): same with the log-domain posterior, eps 1e-30 (elbo.py:127-157, helpers.py:772-781)
+ *  mode 2  KL prior rows: KL(limit || x_0 Qbar_T), both apply_mask-ed (elbo.py:197-238, helpers.py:115-137)
+ *  mode 3  reconstruction rows: sum true * log_softmax(apply_mask(logits, as_logits)) (elbo.py:182-193, helpers.py:139-151)
+ *  mode 4  sum true * log_softmax(logits), unmasked: the negated CE rows of helpers.ce (helpers.py:153-191)
+ * Tables: modes 0/1 Qa = Q_t, Qb = Qbar_{t-1} per graph (B,K,K), q_per_graph = 1; mode 2 Qa = Qbar_T as one (K,K) table
+ * (q_per_graph = 0) and lim_* the limit distributions (K).  mask_x / mask_e: per-node free masks (da_free_masks);
+ * pair (i,j) is free when mask_e[i] & mask_e[j].  Unused pointers may be NULL. */
+int da_elbo_rows(int mode, const float* true_X, const float* true_E, const float* zt_X, const float* zt_E,
+                 const float* logits_X, const float* logits_E, const float* Qa_x, const float* Qb_x, const float* Qa_e,
+                 const float* Qb_e, int q_per_graph, const float* lim_x, const float* lim_e, const uint8_t* mask_x,
+                 const uint8_t* mask_e, float eps, float* rows_X, float* rows_E, int B, int n, int kx, int ke, void* stream);
+
+/* helpers.mean_without_masked (utils/diffusion/helpers.py:59-106), device part: out (B,4) = per graph the sum of rows_X
+ * over free nodes, their count, the sum of rows_E over free pairs, their count (the divisions are the caller's). */
+int da_masked_sums(const float* rows_X, const float* rows_E, const uint8_t* mask_x, const uint8_t* mask_e, float* out, int B,
+                   int n, void* stream);
+
 /* ---- L2 denoiser (graph transformer) -------------------------------------------------------------------------------
  * Hidden edge features travel between these calls as bf16 (B,n,n,de); node features X and globals y stay fp32.
  * Weights arrive pre-packed by diffalign_amd/pack.py: "blob" = MFMA fragments (1 KiB each, lane-linear, bf16) followed
