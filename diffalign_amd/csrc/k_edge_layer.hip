@@ -524,46 +524,6 @@ __global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, 
   out[t] = o;
 }
 
-// per-graph pooled statistics of the bf16 edge tensor (Etoy, neuralnet/layers.py:31-47): partial sums per chunk
-//   out[b][chunk][4][DE] = (sum, sum of squares, min, max) over the chunk's pairs (padding and diagonal included)
-template <int DE>
-__global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, int n, int nchunk) {
-  constexpr int G = DE / 8;            // 16-byte groups per row
-  constexpr int RL = 256 / G;          // rows handled concurrently
-  const int b = blockIdx.y, ch = blockIdx.x;
-  const size_t N = (size_t)n * n;
-  const size_t per = (N + nchunk - 1) / nchunk;
-  const size_t p0 = ch * per, p1 = min(N, p0 + per);
-  const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  float s[8], ss[8], mn[8], mx[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; mn[e] = INFINITY; mx[e] = -INFINITY; }
-  const bf16_t* base = E + (size_t)b * N * DE;
-  for (size_t p = p0 + rl; p < p1; p += RL) {
-    const uint4 u = *reinterpret_cast<const uint4*>(base + p * DE + 8 * g);
-    const unsigned d[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
-      s[e] += v; ss[e] = fmaf(v, v, ss[e]); mn[e] = fminf(mn[e], v); mx[e] = fmaxf(mx[e], v);
-    }
-  }
-  __shared__ float red[4][256][8 + 1];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; red[2][threadIdx.x][e] = mn[e]; red[3][threadIdx.x][e] = mx[e]; }
-  __syncthreads();
-  if (threadIdx.x < DE) {
-    const int c = threadIdx.x, gg = c / 8, e = c % 8;
-    float a0 = 0.f, a1 = 0.f, a2 = INFINITY, a3 = -INFINITY;
-    for (int k = 0; k < RL; ++k) {
-      const int t = k * G + gg;
-      a0 += red[0][t][e]; a1 += red[1][t][e]; a2 = fminf(a2, red[2][t][e]); a3 = fmaxf(a3, red[3][t][e]);
-    }
-    float* o = out + ((size_t)(b * nchunk + ch) * 4) * DE;
-    o[c] = a0; o[DE + c] = a1; o[2 * DE + c] = a2; o[3 * DE + c] = a3;
-  }
-}
-
 // ===================================================================================================
 template <int DE, int DX, int DFF, int NT_>
 static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
@@ -605,17 +565,6 @@ int da_kv_pack(const float* K, const float* V, int ldkv, void* out, int B, int n
   size_t tot = (size_t)B * ((n + 31) / 32) * (dx / 32) * 4 * 64;
   k_kv_pack<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(K, V, ldkv, (uint4*)out, B, n, dx);
   DA_CHECK_LAUNCH("da_kv_pack");
-  return DA_OK;
-}
-
-int da_edge_stats(const void* E_bf16, float* partials, int B, int n, int de, int nchunk, void* stream) {
-  DA_CHECK_ARG(nchunk >= 1, "da_edge_stats: nchunk < 1");
-  if (B == 0 || n == 0) return DA_OK;
-  dim3 grid(nchunk, B);
-  if (de == 64) k_e_stats<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
-  else if (de == 32) k_e_stats<32><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
-  else { da_set_error("da_edge_stats: de=%d not built (32, 64)", de); return DA_ERR_UNSUPPORTED; }
-  DA_CHECK_LAUNCH("da_edge_stats");
   return DA_OK;
 }
 
