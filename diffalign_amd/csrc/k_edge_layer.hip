@@ -162,7 +162,12 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
   const unsigned vv[8] = {kv[2].x, kv[2].y, kv[2].z, kv[2].w, kv[3].x, kv[3].y, kv[3].z, kv[3].w};
   float tmax = -INFINITY;
   int fs = 0;                                       // next feed step
+#ifdef EXP_NOINTERLEAVE
+#pragma unroll
+  for (; fs < Gemm1Feed<DE, DX, DFF>::N; ++fs) feed.step(fs);
+#else
   feed.step(fs++);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
