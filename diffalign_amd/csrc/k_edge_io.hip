@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
       const float* pji = E_in + (((size_t)b * n + jc) * n + i) * de_in;
       // symmetric input tile (the diffusion state always is): mlp(E_ij) == mlp(E_ji) bit for bit, one evaluation is enough
       bool same = true;
+#ifndef EXP_IN_NOMIRROR
       for (int c = 8 * h; c < min(de_in, 8 * h + 8); ++c) same = same && (pij[c] == pji[c]);
+#endif
       const bool sym_tile = __all(same);               // wave-uniform
       mlp_in_chain<DE, HE>(pij, de_in, h, lane, sW0, sW1, sP, o);
       const float pm = (mi && jvalid && nm[b * n + jc] && jc != i) ? 1.f : 0.f;
@@ -103,7 +105,11 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
         uint4 st = {pack_bf16(o[mt][4 * g0 + 0], o[mt][4 * g0 + 1]), pack_bf16(o[mt][4 * g0 + 2], o[mt][4 * g0 + 3]),
                     pack_bf16(o[mt][4 * g0 + 4], o[mt][4 * g0 + 5]), pack_bf16(o[mt][4 * g0 + 6], o[mt][4 * g0 + 7])};
         row16_to_corder(st);
+#ifdef EXP_IN_NOSTORE
+        if (jvalid && st.x == 0x12345u) *reinterpret_cast<uint4*>(E_out + ((size_t)row * n + jl) * DE + 16 * u + 8 * h) = st;
+#else
         if (jvalid) *reinterpret_cast<uint4*>(E_out + ((size_t)row * n + jl) * DE + 16 * u + 8 * h) = st;
+#endif
       }
     }
   }

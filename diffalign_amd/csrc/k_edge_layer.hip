@@ -191,10 +191,17 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
     }
     pin(y);
     e1[2 * k] = y.x; e1[2 * k + 1] = y.y;
+#if !defined(EXP_LATEKV) && !defined(EXP_NOKV)
+    if (k == 3) kv[0] = kv_next[0];                  // first K word group is dead: fetch the next block's now
+#endif
     if (k & 1) { pin(tmax); feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
   }
 #ifndef EXP_NOKV
+#ifndef EXP_LATEKV
+  kv[1] = kv_next[64];                             // second K word group (the first was refilled after key 7 of 16)
+#else
   kv[0] = kv_next[0]; kv[1] = kv_next[64];          // K words are dead: fetch the next block's in place
+#endif
 #endif
   // online softmax in the log2 domain: p = 2^(y*log2e - m*log2e)
   const float mnew = fmaxf(sm_m, tmax);
@@ -220,12 +227,19 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
     f32x2 z = y * f2c + baf;                                     // FiLM multiplicative part (+ the deferred e_add bias)
     pin(z);
     e1[2 * k] = z.x; e1[2 * k + 1] = z.y;
+#if !defined(EXP_LATEKV) && !defined(EXP_NOKV)
+    if (k == 3) kv[2] = kv_next[128];
+#endif
     if (k & 1) { pin(psum); pin(pv); feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
   }
 #pragma unroll
   for (; fs < Gemm1Feed<DE, DX, DFF>::N; ++fs) feed.step(fs);      // (DE = 64: none left)
 #ifndef EXP_NOKV
+#ifndef EXP_LATEKV
+  kv[3] = kv_next[192];
+#else
   kv[2] = kv_next[128]; kv[3] = kv_next[192];       // V words likewise
+#endif
 #endif
   sm_l = fmaf(sm_l, sc, psum.x + psum.y);
   sm_a = fmaf(sm_a, sc, pv.x + pv.y);
