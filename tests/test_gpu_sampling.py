@@ -98,3 +98,45 @@ def test_sampling_properties_at_max_atoms():
     assert torch.equal(a.E.cpu()[fe], true['E'][fe])
     pad = ~true['node_mask']
     assert bool((a.X.cpu()[pad].argmax(-1) == 0).all())
+
+
+def test_marginal_sampling_at_twice_max_atoms():
+    """BASELINE.json configs[4]: transition='marginal' (dense marginal Qbar_t posterior), n = 600 (the edge-tensor
+    bandwidth stress), full dims, 2 layers, 3 steps: same size-independent properties as above."""
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    dims = dict(n_layers=2, hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
+                hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
+    torch.manual_seed(0)
+    cfg = make_cfg(dims, T_=500, T_eval=5, extra=True)
+    cfg.diffusion.transition = 'marginal'
+    info = make_info()
+    g = torch.Generator().manual_seed(11)
+    info.node_types = torch.rand(KX, generator=g) + 0.1       # a fixed seeded probability vector over the classes
+    info.edge_types = torch.rand(KE, generator=g) + 0.1
+    model = DiscreteDenoisingDiffusion(cfg, info, device=D).eval()
+    B, n = 1, 600
+    true = S.make_reaction_batch(B, n, seed=9, P=None)
+    pos = S.shared_pos_encodings(true, 256, seed=6).to(D)
+    model.pos_encodings_fn = lambda zt: pos
+    xe, ye = torch.rand(B, n, 8, generator=g).to(D), torch.rand(B, 12, generator=g).to(D)
+    model.extra_features_fn = lambda zt: (xe, ye)
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    outs = [model.sample_one_batch(data=data, noise_fn=lambda c, shp: S.exp_noise(shp, 300 + c)) for _ in range(2)]
+    a, b = outs
+    assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E)
+    assert torch.equal(a.E, a.E.transpose(1, 2))
+    assert bool((a.X.sum(-1) == 1).all()) and bool((a.E.sum(-1) == 1).all())
+    cls = true['X'].argmax(-1)
+    ar = torch.arange(n)[None].expand(B, n)
+    spos = torch.where(cls == 28, ar, torch.full_like(ar, -1)).max(-1).values
+    fixed = ar >= spos[:, None]
+    assert torch.equal(a.X.cpu()[fixed], true['X'][fixed])
+    fe = fixed[:, :, None] | fixed[:, None, :]
+    assert torch.equal(a.E.cpu()[fe], true['E'][fe])
+    # masked states of the marginal family are never drawn on free nodes / pairs (noise_schedule.py:88-134)
+    free = ~fixed & true['node_mask']
+    assert not bool(((a.X.cpu().argmax(-1) == 28) & free).any()) and not bool(((a.X.cpu().argmax(-1) == 0) & free).any())
+    fee = free[:, :, None] & free[:, None, :]
+    assert not bool((a.E.cpu().argmax(-1)[fee] >= 4).any())
