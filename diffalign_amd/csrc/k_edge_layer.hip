@@ -67,6 +67,8 @@ struct EdgeLayerArgs {
   const uint4* blob;      // packed layer weights (EdgeCfg layout)
   float qscale;           // 1/sqrt(df)
   int B, n;
+  float* split;           // tail-split scratch [8][slots_per_xcd][3][DX] (running max, sum, weighted sum) or null
+  int slots_per_xcd;
   int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
 };
 
@@ -78,6 +80,26 @@ struct EdgeLayerArgs {
 //    Z = f2c*y' + f2c*ba (one packed fma); masked keys carry y' = -ba so that their true score is 0;
 //  * all elementwise work is written on float pairs so that it maps to v_pk_{mul,fma,add}_f32;
 //  * the high halves of the packed K/V words are used as fp32 without masking (k_kv_pack compensates the rounding).
+// Work partition of the persistent grid.  Rows are cut into 8 contiguous chunks, one per XCD (workgroups with equal
+// blockIdx % 8 share an XCD and its L2).  Inside a chunk the W = (gridDim/8) * waves-per-workgroup waves take whole rows
+// round-robin; with a split scratch the rows of the last, incomplete round are cut into runs of key tiles instead, so
+// that every wave gets the same amount of work (at B*n = 19,200 rows and 2,048 waves the incomplete round would keep
+// 37 % of the waves busy for a full row time).  A run leaves its online-softmax state in the scratch; k_edge_split_merge
+// folds the runs of a row.  Both kernels (and the host sizing) use this one definition.
+struct EdgePart {
+  int row_begin, row_end, W, nfull, rem, tpw;
+  __host__ __device__ EdgePart(int R, int grid_blocks, int NW, int NT, int xcd, bool split) {
+    const int chunk = (R + 7) / 8;
+    row_begin = xcd * chunk; row_end = row_begin + chunk < R ? row_begin + chunk : R;
+    if (row_end < row_begin) row_end = row_begin;
+    W = (grid_blocks >> 3) * NW;
+    const int rows = row_end - row_begin;
+    nfull = split ? rows / W : (rows + W - 1) / W;
+    rem = split ? rows - nfull * W : 0;
+    tpw = rem > 0 ? (rem * NT + W - 1) / W : 0;
+  }
+};
+
 // GEMM1 of one 32-channel block: e1 = E W_mul^T + (1 + b_mul) (bias through the ones k-step), e2 = E W_add^T
 template <int DE, int DX, int DFF>
 __device__ __forceinline__ void gemm1_block(const int cb, const int lane, const uint4 (&eraw)[DE / 16], const uint4* sW1,
@@ -289,17 +311,29 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) onesA[j] = (h == 0 && j < 2) ? (short)0x3F80 : (short)0;
 
-  // XCD-aware persistent row walk: blocks with equal blockIdx%8 share an XCD (L2); give each XCD one contiguous
-  // chunk of rows so a graph's K/V fragments and Q rows stay in that L2.
-  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int chunk = (R + 7) / 8;
-  const int row_begin = xcd * chunk, row_end = min(R, row_begin + chunk);
+  // XCD-aware persistent walk over work units (EdgePart): whole rows, then runs of key tiles of the split rows
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const EdgePart part(R, gridDim.x, NW, NT, xcd, a.split != nullptr);
+  const int wid = bi * NW + wave;
+  int kfull = 0;
+  int u0 = wid * part.tpw, u1 = min(part.rem * NT, u0 + part.tpw);
 
   if (wave >= NW / 2) {
     if (a.prio) __builtin_amdgcn_s_setprio(1);
     for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(1);
   }
-  for (int row = row_begin + bi * NW + wave; row < row_end; row += bpx * NW) {
+  for (;;) {
+    int row, jt0, jt1, slot = -1;
+    if (kfull < part.nfull) {
+      row = part.row_begin + kfull * part.W + wid; jt0 = 0; jt1 = NT; ++kfull;
+      if (row >= part.row_end) continue;
+    } else if (u0 < u1) {
+      const int rl = u0 / NT;
+      jt0 = u0 - rl * NT; jt1 = min(NT, jt0 + (u1 - u0));
+      row = part.row_begin + part.nfull * part.W + rl; slot = u0; u0 += jt1 - jt0;
+    } else {
+      break;
+    }
     const int b = row / n, i = row - b * n;
     const bool mi = a.node_mask[row] != 0;
     // online-softmax state per channel block (running max, sum, weighted sum): registers (the cb loop is unrolled)
@@ -321,16 +355,16 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     // replace the current ones as soon as they are dead, and the key-mask byte is fetched one tile ahead.
     uint4 eraw[C::KS1];
     {
-      const int j0c = min(r, n - 1);
+      const int j0c = min(jt0 * 32 + r, n - 1);
 #pragma unroll
       for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
     }
     const uint4* kvrow = a.KV + ((size_t)b * NT * C::NCB) * 4 * 64 + lane;
     uint4 kvA[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) kvA[e] = kvrow[e * 64];
-    uint8_t nmb = a.node_mask[b * n + min(r, n - 1)];
-    for (int jt = 0; jt < NT; ++jt) {
+    for (int e = 0; e < 4; ++e) kvA[e] = kvrow[((size_t)jt0 * C::NCB * 4 + e) * 64];
+    uint8_t nmb = a.node_mask[b * n + min(jt0 * 32 + r, n - 1)];
+    for (int jt = jt0; jt < jt1; ++jt) {
       const int jl = jt * 32 + r;
       const bool jvalid = jl < n;
       const bool mj = jvalid && (nmb != 0);
@@ -490,7 +524,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #endif
       }
     }
-    // ---- end of the query row: merge the two lane halves' softmax states, write the x_out input
+    // ---- end of the unit: merge the two lane halves' softmax states; a whole row writes the x_out input, a run of a
+    // split row leaves (max, sum, weighted sum) for k_edge_split_merge
 #pragma unroll
     for (int cb = 0; cb < C::NCB; ++cb) {
       const float m_ = sm_m[cb], l_ = sm_l[cb], a_ = sm_a[cb];
@@ -500,9 +535,38 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       const float l = l_ * s0 + lo * s1, av = a_ * s0 + ao * s1;
       if (h == 0) {
         const int c = 32 * cb + r;
-        a.newX_in[(size_t)row * DX + c] = fmaf(a.yx2p1[(size_t)b * DX + c], av / l, a.yx1[(size_t)b * DX + c]);
+        if (slot < 0) {
+          a.newX_in[(size_t)row * DX + c] = fmaf(a.yx2p1[(size_t)b * DX + c], av / l, a.yx1[(size_t)b * DX + c]);
+        } else {
+          float* o = a.split + ((size_t)(xcd * a.slots_per_xcd + slot) * 3) * DX + c;
+          o[0] = M; o[DX] = l; o[2 * DX] = av;
+        }
       }
     }
+  }
+}
+
+// folds the runs of every split row (EdgePart) into the x_out input: newX_in = yx1 + yx2p1 * (sum_r a_r e^{m_r-M}) / (sum_r l_r e^{m_r-M})
+__global__ void __launch_bounds__(256) k_edge_split_merge(const float* split, int slots_per_xcd, const float* yx1, const float* yx2p1,
+                                                          float* newX_in, int R, int n, int DX, int grid_blocks, int NW, int max_rem) {
+  const int NT = (n + 31) / 32;
+  const int xcd = blockIdx.x / max_rem, rl = blockIdx.x % max_rem;
+  const EdgePart part(R, grid_blocks, NW, NT, xcd, true);
+  if (rl >= part.rem) return;
+  const int row = part.row_begin + part.nfull * part.W + rl;
+  const int b = row / n;
+  for (int c = threadIdx.x; c < DX; c += blockDim.x) {
+    float M = -INFINITY, L = 0.f, A = 0.f;
+    for (int u = rl * NT, end = (rl + 1) * NT; u < end;) {
+      const float* p = split + ((size_t)(xcd * slots_per_xcd + u) * 3) * DX + c;
+      const float m = p[0], l = p[DX], av = p[2 * DX];
+      const float Mn = fmaxf(M, m);
+      const float s0 = __expf(M - Mn), s1 = __expf(m - Mn);
+      L = L * s0 + l * s1; A = A * s0 + av * s1; M = Mn;
+      const int seg_end = (u / part.tpw + 1) * part.tpw;
+      u = seg_end < end ? seg_end : end;
+    }
+    newX_in[(size_t)row * DX + c] = fmaf(yx2p1[(size_t)b * DX + c], A / L, yx1[(size_t)b * DX + c]);
   }
 }
 
@@ -558,14 +622,30 @@ static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s
   return DA_OK;
 }
 static int g_edge_threads = 0;
-template <int DE, int DX, int DFF>
-static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+static int edge_threads() {
   if (g_edge_threads == 0) {
     const char* e = getenv("DA_EDGE_THREADS");
     g_edge_threads = (e && atoi(e) == 256) ? 256 : 512;   // default: 8 waves/workgroup = 2 waves per SIMD
   }
-  if (g_edge_threads == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
+  return g_edge_threads;
+}
+template <int DE, int DX, int DFF>
+static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+  if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
   return launch_edge_nt<DE, DX, DFF, 256>(a, grid_blocks, s);
+}
+static int edge_grid(int rows) {
+  int grid = 256;                                   // one persistent workgroup per CU
+  int need = ((rows + 3) / 4 + 7) / 8 * 8;          // enough workgroups for one row per wave
+  if (need < grid) grid = need < 8 ? 8 : need;
+  return grid;
+}
+// largest number of split rows of any XCD chunk (0: the rows divide evenly, nothing to split)
+static int edge_max_rem(int rows, int n) {
+  const int NT = (n + 31) / 32, grid = edge_grid(rows), NW = edge_threads() / 64;
+  int mx = 0;
+  for (int x = 0; x < 8; ++x) { const EdgePart p(rows, grid, NW, NT, x, true); if (p.rem > mx) mx = p.rem; }
+  return mx;
 }
 
 extern "C" {
@@ -588,26 +668,44 @@ int da_kv_pack(const float* K, const float* V, int ldkv, void* out, int B, int n
 }
 
 // Fused edge side of one XEyTransformerLayer (see file header).  All pointers device; E bf16.
+// bytes of the tail-split scratch da_edge_layer can use for this problem size (0: no split needed)
+long long da_edge_split_scratch_bytes(int B, int n, int dx) {
+  if (B <= 0 || n <= 0) return 0;
+  const int NT = (n + 31) / 32;
+  return (long long)8 * edge_max_rem(B * n, n) * NT * 3 * dx * (long long)sizeof(float);
+}
+
 int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                   const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
-                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* stream) {
+                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                  long long split_scratch_bytes, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   if (B == 0 || n == 0) return DA_OK;
+  const int rows = B * n, NT = (n + 31) / 32;
+  const int grid = edge_grid(rows);
+  const int max_rem = edge_max_rem(rows, n);
+  float* split = nullptr;
+  if (split_scratch && max_rem > 0) {
+    DA_CHECK_ARG(split_scratch_bytes >= da_edge_split_scratch_bytes(B, n, dx),
+                 "da_edge_layer: split scratch of %lld B is smaller than da_edge_split_scratch_bytes", split_scratch_bytes);
+    split = (float*)split_scratch;
+  }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, 0, 0};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0};
   { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
     const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2); }
-  const int rows = B * n;
-  int grid = 256;                                   // one persistent workgroup per CU
-  int need = ((rows + 3) / 4 + 7) / 8 * 8;   // enough workgroups for one row per wave
-  if (need < grid) grid = need < 8 ? 8 : need;
   int rc;
   if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
   else if (de == 32 && dx == 64 && dff == 64) rc = launch_edge<32, 64, 64>(a, grid, (hipStream_t)stream);
   else { da_set_error("da_edge_layer: dims (de=%d, dx=%d, dffE=%d) not built; built: (64,256,128), (32,64,64)", de, dx, dff); return DA_ERR_UNSUPPORTED; }
   if (rc) return rc;
   DA_CHECK_LAUNCH("da_edge_layer");
+  if (split) {
+    k_edge_split_merge<<<8 * max_rem, 256, 0, (hipStream_t)stream>>>(split, max_rem * NT, yx1, yx2p1, newX_in, rows, n, dx, grid,
+                                                                    edge_threads() / 64, max_rem);
+    DA_CHECK_LAUNCH("da_edge_layer (split merge)");
+  }
   return DA_OK;
 }
 

@@ -3,6 +3,7 @@ issues the C-ABI calls of include/diffalign_hip.h in order.  PyTorch only owns m
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional
 
@@ -13,6 +14,7 @@ from . import pack
 
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
+SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
 
@@ -121,12 +123,16 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
     L.check(lib.da_kv_pack(C.c_void_p(qkv.data_ptr() + dx * fsz), C.c_void_p(qkv.data_ptr() + 2 * dx * fsz), _i(3 * dx),
                            L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
     E_out = torch.empty_like(E_bf16)
+    lib.da_edge_split_scratch_bytes.restype = C.c_longlong
+    nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
+    split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(R, dx, device=dev)
     if PROFILE_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
     L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(qkv), _i(3 * dx), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
                               L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
-                              C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe), S),
+                              C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
+                              L.ptr(split), C.c_longlong(split.numel() if split is not None else 0), S),
             'da_edge_layer')
     if PROFILE_EVENTS is not None:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))

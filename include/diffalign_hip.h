@@ -152,7 +152,12 @@ int da_kv_pack(const float* K, const float* V, int ldkv, void* kv_frag, int B, i
  * the input of x_out.  E_in != E_out. */
 int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* kv_frag, const uint8_t* node_mask,
                   const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
-                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* stream);
+                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch /* nullable */,
+                  long long split_scratch_bytes, void* stream);
+/* Load balance of da_edge_layer's persistent grid: with a scratch of this many bytes (0: not needed for this size) the
+ * query rows of the last, incomplete round are cut into runs of key tiles over all waves and folded by a small second
+ * kernel; without it (NULL) whole rows only.  Results are identical up to the fp32 order of the softmax merge. */
+long long da_edge_split_scratch_bytes(int B, int n, int dx);
 
 /* Pooled-statistics partials (sum, sum of squares, min, max per channel) for Etoy / Xtoy (layers.py:15-47):
  * partials are (B, nchunk, 4, d) fp32 and are combined (fp64, unbiased std) inside da_y_update. */
