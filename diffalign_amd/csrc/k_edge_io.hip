@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(256) k_edge_out(const bf16_t* __restrict__ E_h
 }
 
 // ===================================================================================================
-static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
+#ifndef EXP_IOGRID_CAP
+#define EXP_IOGRID_CAP 2048
+#endif
+static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
 
 template <int DE, int HE>
 static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s) {

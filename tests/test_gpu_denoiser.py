@@ -136,8 +136,9 @@ def test_model_full_dims_one_layer_golden():
     assert agree >= 0.99, agree
 
 
-@pytest.mark.parametrize('dims,L_,B,n,P', [(FULL, 9, 2, 64, None), (TINY, 2, 4, 24, None), (FULL, 2, 1, 300, 142)],
-                         ids=['full9', 'tiny2', 'full2_n300'])
+@pytest.mark.parametrize('dims,L_,B,n,P', [(FULL, 9, 2, 64, None), (TINY, 2, 4, 24, None), (FULL, 2, 1, 300, 142),
+                                           (TINY, 2, 3, 33, 5), (FULL, 1, 1, 97, None), (TINY, 1, 37, 40, None)],
+                         ids=['full9', 'tiny2', 'full2_n300', 'tiny_n33_mostly_padding', 'full_n97_B1', 'tiny_B37'])
 def test_model_vs_oracle(dims, L_, B, n, P):
     m, sd = build(dims, L_, seed=21)
     hd = dims['hidden_dims']
