@@ -34,17 +34,30 @@ __global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, in
     for (int k = 0; k < U; ++k) fold(u[k]);
   }
   for (; p < p1; p += RL) fold(*reinterpret_cast<const uint4*>(base + p * DE));
-  __shared__ float red[4][256][8 + 1];
+  // fold the row-lanes: lanes with equal channel group g inside a wave (xor 8, 16, 32 for DE = 64), then the 4 waves via LDS
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; red[2][threadIdx.x][e] = mn[e]; red[3][threadIdx.x][e] = mx[e]; }
+  for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += __shfl_xor(s[e], off); ss[e] += __shfl_xor(ss[e], off);
+      mn[e] = fminf(mn[e], __shfl_xor(mn[e], off)); mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], off));
+    }
+  }
+  __shared__ float red[4][4][DE];                  // [wave][stat][channel]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[wave][0][8 * lane + e] = s[e]; red[wave][1][8 * lane + e] = ss[e];
+      red[wave][2][8 * lane + e] = mn[e]; red[wave][3][8 * lane + e] = mx[e];
+    }
+  }
   __syncthreads();
   if (threadIdx.x < DE) {
-    const int c = threadIdx.x, gg = c / 8, e = c % 8;
+    const int c = threadIdx.x;
     float a0 = 0.f, a1 = 0.f, a2 = INFINITY, a3 = -INFINITY;
-    for (int k = 0; k < RL; ++k) {
-      const int t = k * G + gg;
-      a0 += red[0][t][e]; a1 += red[1][t][e]; a2 = fminf(a2, red[2][t][e]); a3 = fmaxf(a3, red[3][t][e]);
-    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a0 += red[w][0][c]; a1 += red[w][1][c]; a2 = fminf(a2, red[w][2][c]); a3 = fmaxf(a3, red[w][3][c]); }
     float* o = out + ((size_t)(b * nchunk + ch) * 4) * DE;
     o[c] = a0; o[DE + c] = a1; o[2 * DE + c] = a2; o[3 * DE + c] = a3;
   }
