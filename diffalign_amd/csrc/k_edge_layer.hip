@@ -590,20 +590,7 @@ __global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, 
     const int j = 32 * jt + crow(8 * half2 + e, h);
     v[e] = j < n ? src[((size_t)b * n + j) * ldkv + 32 * cb + r] : 0.f;
   }
-  // The edge kernel reads the high half of each word as an fp32 WITHOUT masking the low half off, so the high half is
-  // chosen such that the whole word, seen as fp32, is the value nearest to v[odd] (error <= half a bf16 ulp, as for RNE).
-  // Word order: words (2m, 2m+1) carry elements (4m, 4m+1) in their low halves and (4m+2, 4m+3) in their high halves.
-  unsigned w[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mm = q >> 1, t2 = q & 1;
-    const unsigned lo = pack_bf16(v[4 * mm + t2], 0.f) & 0xffffu;
-    const unsigned tb = __builtin_bit_cast(unsigned, v[4 * mm + 2 + t2]);
-    const unsigned sgn = tb & 0x80000000u, mag = tb & 0x7fffffffu;
-    const unsigned hm = mag >= lo ? (mag - lo + 0x8000u) >> 16 : 0u;
-    w[q] = sgn | (hm << 16) | lo;
-  }
-  uint4 o = {w[0], w[1], w[2], w[3]};
+  const uint4 o = kv_words(v);   // word order and rounding: mfma_util.h
   out[t] = o;
 }
 

@@ -49,3 +49,21 @@ __device__ __forceinline__ bf16x8 ident_frag(int s, int r, int h) {
   for (int j = 0; j < 8; ++j) f[j] = (r == 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) ? (short)0x3F80 : (short)0;
   return f;
 }
+
+// K/V operand words of the edge-layer kernel: 8 consecutive accumulator-order values -> 4 dwords.  Words (2m, 2m+1)
+// carry elements (4m, 4m+1) in their low halves and (4m+2, 4m+3) in their high halves.  The kernel reads a high half as an
+// fp32 WITHOUT masking the low half off, so the high half is chosen such that the whole word, seen as fp32, is the value
+// nearest to the element (error <= half a bf16 ulp, as for round-to-nearest-even).
+__device__ __forceinline__ uint4 kv_words(const float (&v)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mm = q >> 1, t2 = q & 1;
+    const unsigned lo = pack_bf16(v[4 * mm + t2], 0.f) & 0xffffu;
+    const unsigned tb = __builtin_bit_cast(unsigned, v[4 * mm + 2 + t2]);
+    const unsigned sgn = tb & 0x80000000u, mag = tb & 0x7fffffffu;
+    const unsigned hm = mag >= lo ? (mag - lo + 0x8000u) >> 16 : 0u;
+    w[q] = sgn | (hm << 16) | lo;
+  }
+  return uint4{w[0], w[1], w[2], w[3]};
+}

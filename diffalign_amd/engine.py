@@ -66,6 +66,7 @@ class PackedModel:
             self.skip = (f32(g('skip_scaling')), f32(g('skip_scaling_2')))
         lib.da_x_post_blob_bytes.restype = C.c_longlong
         self.fused_x = lib.da_x_post_blob_bytes(_i(self.dx), _i(self.dffx)) > 0     # else: the unfused da_linear chain
+        self.fused_qkv = self.dx in (256, 64)                                       # else: da_linear + da_kv_pack
         self.layers = []
         for l in range(n_layers):
             p = f'tf_layers.{l}'
@@ -115,13 +116,18 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
     yx1 = torch.empty(B, dx, device=dev); yx2p1 = torch.empty(B, dx, device=dev)
     L.check(lib.da_y_film(L.ptr(y), lw['film'].arr, L.ptr(ye2p1), L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), _i(B), _i(dy), _i(dx),
                           _i(de), S), 'da_y_film')
-    qkv = torch.empty(R, 3 * dx, device=dev)
-    _linear(X, dx, lw['Wqkv'], lw['bqkv'], nm_u8, qkv, 3 * dx, R, 3 * dx, dx, False)
     lib.da_kv_frag_bytes.restype = C.c_longlong
     kvf = torch.empty(lib.da_kv_frag_bytes(_i(B), _i(n), _i(dx)), dtype=torch.uint8, device=dev)
-    fsz = 4
-    L.check(lib.da_kv_pack(C.c_void_p(qkv.data_ptr() + dx * fsz), C.c_void_p(qkv.data_ptr() + 2 * dx * fsz), _i(3 * dx),
-                           L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
+    if pm.fused_qkv:
+        Qm = torch.empty(R, dx, device=dev); ldq = dx
+        L.check(lib.da_qkv_frag(L.ptr(X), L.ptr(lw['Wqkv']), L.ptr(lw['bqkv']), L.ptr(nm_u8), L.ptr(Qm), L.ptr(kvf), _i(B), _i(n),
+                                _i(dx), S), 'da_qkv_frag')
+    else:
+        Qm = torch.empty(R, 3 * dx, device=dev); ldq = 3 * dx
+        _linear(X, dx, lw['Wqkv'], lw['bqkv'], nm_u8, Qm, 3 * dx, R, 3 * dx, dx, False)
+        fsz = 4
+        L.check(lib.da_kv_pack(C.c_void_p(Qm.data_ptr() + dx * fsz), C.c_void_p(Qm.data_ptr() + 2 * dx * fsz), _i(3 * dx),
+                               L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
     E_out = torch.empty_like(E_bf16)
     lib.da_edge_split_scratch_bytes.restype = C.c_longlong
     nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
@@ -129,7 +135,7 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
     newX_in = torch.empty(R, dx, device=dev)
     if PROFILE_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
-    L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(qkv), _i(3 * dx), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
+    L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(ldq), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
                               L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
                               C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
                               L.ptr(split), C.c_longlong(split.numel() if split is not None else 0), S),

@@ -143,6 +143,12 @@ int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, c
 int da_y_film(const float* y, const float* const* w /*host*/, float* ye2p1, float* ebias, float* yx1, float* yx2p1, int B,
               int dy, int dx, int de, void* stream);
 
+/* q, k, v projections of one layer fused with the K/V fragment packing (layers.py:217-223): Q (B*n, dx) fp32 = q(X)*mask,
+ * kv_frag = K, V in da_kv_pack's layout (da_kv_frag_bytes).  W_bf16 = cat(q,k,v).weight packed like da_linear's operand,
+ * bias = cat of the three biases (3*dx).  Built: dx = 256, 64. */
+int da_qkv_frag(const float* X, const void* W_bf16, const float* bias, const uint8_t* node_mask, float* Q, void* kv_frag,
+                int B, int n, int dx, void* stream);
+
 /* K,V (fp32 (B*n, ldkv), masked) -> bf16 fragment layout read by da_edge_layer. */
 int da_kv_pack(const float* K, const float* V, int ldkv, void* kv_frag, int B, int n, int dx, void* stream);
 
