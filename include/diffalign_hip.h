@@ -191,6 +191,14 @@ int da_x_out_finish(const float* lin, int ldl, const float* X_in, int dx_in, con
 int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
                 const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream);
 
+/* The same output stage in two passes, each hidden edge row read once and mlp_out_E evaluated once per ordered pair
+ * (da_edge_out evaluates both orientations in one pass and reads the hidden tensor twice): G (B,n,n,8) fp32 is a scratch
+ * the caller owns.  da_edge_out_g: G = mlp_out_E(E_h) (transformer_model_with_y.py:672-673); da_edge_out_finish:
+ * logits = sym((G + E_in[..., :ke]) * offdiag) [+ skip] (:674-704).  Bit-identical to da_edge_out. */
+int da_edge_out_g(const void* E_h, const void* blob, float* G, int B, int n, int de, int he, void* stream);
+int da_edge_out_finish(const float* G, const float* E_in, int de_in, const int* src, const float* skip1, const float* skip2,
+                       float* E_logits, int B, int n, int ke, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
