@@ -15,6 +15,7 @@ from . import pack
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
 TWO_PASS_EDGE_OUT = os.environ.get('DA_EDGE_OUT_2PASS', '1') != '0'   # da_edge_out_g + da_edge_out_finish instead of da_edge_out
+SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '0') == '1'   # y branch of every layer on a second HIP stream (measured: no gain, off)
 SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
@@ -106,8 +107,9 @@ def edge_stats(E_bf16, B, n, de):
     return st
 
 
-def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
-    """One XEyTransformerLayer (neuralnet/layers.py:330-361).  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32."""
+def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n):
+    """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
+    fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'."""
     dev = X.device
     dx, de, dy = pm.dx, pm.de, pm.dy
     R = B * n
@@ -159,12 +161,44 @@ def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
         _linear(hbuf, pm.dffx, lw['W2'], lw['b2'], None, ff, dx, R, dx, pm.dffx, False)
         L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
                 'da_add_layernorm')
+    return X2, E_out
+
+
+def layer_y(pm: PackedModel, lw: dict, X, y, estats, B, n):
+    """y branch of one XEyTransformerLayer (layers.py:277-281, 353-359): pooled statistics of the layer's INPUT X and E,
+    y_out, the two LayerNorms and the y FFN.  Independent of the X / E branches of the same layer."""
+    dev = X.device
+    dx, de, dy = pm.dx, pm.de, pm.dy
+    lib = L.lib()
+    S = L.stream()
     y2 = torch.empty(B, dy, device=dev)
     xst = torch.empty(B, N_XSTAT_CHUNKS, 4, dx, device=dev)
     L.check(lib.da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(dx), _i(N_XSTAT_CHUNKS), S), 'da_x_stats')
     L.check(lib.da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(y2), _i(B), _i(n), _i(dx),
                             _i(de), _i(dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(N_STAT_CHUNKS), S), 'da_y_update')
-    return X2, E_out, y2
+    return y2
+
+
+def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
+    """One XEyTransformerLayer (neuralnet/layers.py:330-361) on the current stream."""
+    X2, E_out = layer_main(pm, lw, X, E_bf16, y, nm_u8, B, n)
+    return X2, E_out, layer_y(pm, lw, X, y, estats, B, n)
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """Optional second HIP stream for the y branch (DA_SIDE_STREAM=1).  Its pooled statistics are one HBM-bound pass over E
+    and its MLPs use 64 workgroups, so in principle they overlap the q/k/v and node-tail kernels of the X branch; measured
+    at B=64, n=300 in one box: 15.8 ms/step with the side stream, 15.6 without -- the edge kernel owns every CU's registers
+    and the statistics pass saturates HBM, there is nothing left to overlap.  Off by default."""
+    if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
@@ -192,9 +226,21 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
     # ---- layers
+    main, side = torch.cuda.current_stream(), _side_stream(dev)
     for lw in pm.layers:
-        st = edge_stats(Eh, B, n, pm.de)
-        Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
+        if side is None:
+            st = edge_stats(Eh, B, n, pm.de)
+            Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
+            continue
+        ready = main.record_event()                  # X, E, y of this layer are complete on the main stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            y_next = layer_y(pm, lw, Xh, yh, edge_stats(Eh, B, n, pm.de), B, n)
+            y_done = side.record_event()
+        X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n)
+        main.wait_event(y_done)                      # also keeps Xh / Eh alive until the side stream has read them
+        y_next.record_stream(main)
+        Xh, Eh, yh = X_next, E_next, y_next
     # ---- output stage
     h1 = torch.empty(R, pm.hx, device=dev)
     _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)
