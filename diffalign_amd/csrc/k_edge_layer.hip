@@ -32,6 +32,19 @@ __device__ __forceinline__ f32x16 fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) { c[0]
 #define EXP2F(x) __builtin_amdgcn_exp2f(x)
 #endif
 
+// Diagnostic build only (EXP_STAMP): per-wave cycle totals of the tile's segments, s_memtime around each, written to a
+// buffer of their own that nothing else reads (tools/stamp_edge.py).  The product build has no stamp.
+#ifdef EXP_STAMP
+#define NSTAMP 12
+__device__ long long g_stamps[4096 * NSTAMP];
+struct Stamps { long long acc[NSTAMP]; long long prev; };
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); S.acc[i] += t_ - S.prev; S.prev = t_; __builtin_amdgcn_sched_barrier(0); }
+extern "C" int da_debug_read_stamps(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n); }
+#else
+struct Stamps {};
+#define STAMP(i)
+#endif
+
 template <int DE, int DX, int DFF>
 struct EdgeCfg {
   static constexpr int NCB = DX / 32;
@@ -86,6 +99,9 @@ struct EdgeLayerArgs {
 // that every wave gets the same amount of work (at B*n = 19,200 rows and 2,048 waves the incomplete round would keep
 // 37 % of the waves busy for a full row time).  A run leaves its online-softmax state in the scratch; k_edge_split_merge
 // folds the runs of a row.  Both kernels (and the host sizing) use this one definition.
+// (Handing the units out dynamically inside a workgroup, by a ticket counter in LDS, was measured and is 7 % SLOWER:
+// with static shares the older wave of each SIMD pair wins the issue arbitration, finishes its share in 80 % of the time
+// and leaves its partner a stretch alone; balanced pairs that stay in step get less out of the SIMD than that.)
 struct EdgePart {
   int row_begin, row_end, W, nfull, rem, tpw;
   __host__ __device__ EdgePart(int R, int grid_blocks, int NW, int NT, int xcd, bool split) {
@@ -174,7 +190,7 @@ template <int DE, int DX, int DFF, bool MASKED>
 __device__ __forceinline__ void softmax_film_block(const int cb, const int lane, f32x16& e1, const f32x16& e2, const float* sP,
                                                    uint4 (&kv)[4], const uint4* kv_next, const float qc, const float f2c,
                                                    const bool mi, const unsigned nmbits, const unsigned vbits, float& sm_m,
-                                                   float& sm_l, float& sm_a, Gemm1Feed<DE, DX, DFF>& feed) {
+                                                   float& sm_l, float& sm_a, Gemm1Feed<DE, DX, DFF>& feed, Stamps& S) {
   using C = EdgeCfg<DE, DX, DFF>;
   constexpr float LOG2E = 1.4426950408889634f;
   const int r = lane & 31;
@@ -225,6 +241,7 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
   kv[0] = kv_next[0]; kv[1] = kv_next[64];          // K words are dead: fetch the next block's in place
 #endif
 #endif
+  STAMP(7)   // loop 1: Y, running max (+ 5 feed MFMAs)
   // online softmax in the log2 domain: p = 2^(y*log2e - m*log2e)
   const float mnew = fmaxf(sm_m, tmax);
   const float mref2 = ((MASKED && mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
@@ -263,6 +280,7 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
   kv[2] = kv_next[128]; kv[3] = kv_next[192];       // V words likewise
 #endif
 #endif
+  STAMP(8)   // loop 2: exp, sums, FiLM (+ 4 feed MFMAs)
   sm_l = fmaf(sm_l, sc, psum.x + psum.y);
   sm_a = fmaf(sm_a, sc, pv.x + pv.y);
   sm_m = mnew;
@@ -322,6 +340,14 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     if (a.prio) __builtin_amdgcn_s_setprio(1);
     for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(1);
   }
+#ifdef EXP_STAMP
+  Stamps S;
+  for (int q = 0; q < NSTAMP; ++q) S.acc[q] = 0;
+  const long long rt0 = __builtin_amdgcn_s_memrealtime();
+  S.prev = __builtin_readcyclecounter();
+#else
+  Stamps S;
+#endif
   for (;;) {
     int row, jt0, jt1, slot = -1;
     if (kfull < part.nfull) {
@@ -364,6 +390,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) kvA[e] = kvrow[((size_t)jt0 * C::NCB * 4 + e) * 64];
     uint8_t nmb = a.node_mask[b * n + min(jt0 * 32 + r, n - 1)];
+    STAMP(0)   // row setup
     for (int jt = jt0; jt < jt1; ++jt) {
       const int jl = jt * 32 + r;
       const bool jvalid = jl < n;
@@ -388,14 +415,16 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       // wave's own MFMAs and VALU overlap (the two waves of a SIMD do not hide each other's dependency stalls).
       f32x16 e1, e2;
       gemm1_block<DE, DX, DFF>(0, lane, eraw, sW1, sB1, onesA, e1, e2);
+      STAMP(1)   // tile head: E tile to C-order, masks, GEMM1 of block 0
       if (fast) {
 #pragma unroll
         for (int cb = 0; cb < C::NCB; ++cb) {
           f32x16 f1, f2;
           Gemm1Feed<DE, DX, DFF> feed(cb + 1 < C::NCB, cb + 1, lane, eraw, sW1, sB1, onesA, f1, f2);
           softmax_film_block<DE, DX, DFF, false>(cb, lane, e1, e2, sP, kvA, (cb + 1 < C::NCB) ? kvt + (cb + 1) * 4 * 64 : kvn, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi,
-                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed);
+                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed, S);
           gemm2_block<DE, DX, DFF>(cb, lane, e1, sWO, id0, id1, acc2);
+          STAMP(9)   // transpose + GEMM2
           if (cb + 1 < C::NCB) { e1 = f1; e2 = f2; }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -405,13 +434,15 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           f32x16 f1, f2;
           Gemm1Feed<DE, DX, DFF> feed(cb + 1 < C::NCB, cb + 1, lane, eraw, sW1, sB1, onesA, f1, f2);
           softmax_film_block<DE, DX, DFF, true>(cb, lane, e1, e2, sP, kvA, (cb + 1 < C::NCB) ? kvt + (cb + 1) * 4 * 64 : kvn, sQF[32 * cb + r], sQF[DX + 32 * cb + r], mi,
-                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed);
+                                                nmbits, vbits, sm_m[cb], sm_l[cb], sm_a[cb], feed, S);
           gemm2_block<DE, DX, DFF>(cb, lane, e1, sWO, id0, id1, acc2);
+          STAMP(9)   // transpose + GEMM2
           if (cb + 1 < C::NCB) { e1 = f1; e2 = f2; }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(2)   // channel-block loop
       // ---- epilogue of the tile: newE^T + bias, pair mask, residual, LN1
       float sum = 0.f;
 #pragma unroll
@@ -457,6 +488,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(3)   // residual + LN1 (+ next E tile load issue)
       // ---- FFN chained through accumulators:  H^T = relu(W1 Em^T + b1),  O^T = W2 H^T + b2
       bf16x8 emB[C::KS1];
 #pragma unroll
@@ -491,6 +523,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #pragma unroll
         for (int i2 = 0; i2 < 16; ++i2) { o[mt][i2] += acc2[mt][i2]; sum2 += o[mt][i2]; }
       }
+      STAMP(4)   // FFN
       const float mean2 = xhalf_sum(sum2) * (1.f / DE);
       float vs2 = 0.f;
 #pragma unroll
@@ -523,6 +556,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         if (jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
 #endif
       }
+      STAMP(5)   // LN2 + store
     }
     // ---- end of the unit: merge the two lane halves' softmax states; a whole row writes the x_out input, a run of a
     // split row leaves (max, sum, weighted sum) for k_edge_split_merge
@@ -543,7 +577,15 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         }
       }
     }
+    STAMP(6)     // row end
   }
+#ifdef EXP_STAMP
+  if (lane == 0) {
+    const int gw = blockIdx.x * NW + wave;
+    S.acc[11] = __builtin_amdgcn_s_memrealtime() - rt0;
+    for (int q = 0; q < NSTAMP; ++q) g_stamps[gw * NSTAMP + q] = S.acc[q];
+  }
+#endif
 }
 
 // folds the runs of every split row (EdgePart) into the x_out input: newX_in = yx1 + yx2p1 * (sum_r a_r e^{m_r-M}) / (sum_r l_r e^{m_r-M})
