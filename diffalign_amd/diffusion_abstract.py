@@ -34,7 +34,8 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
         self.dataset_info = dataset_infos
         self.eps = 1e-6
         self.device_ = torch.device(device)
-        self.extra_features_fn = None      # callable(z_t) -> (X_extra (B,n,8), y_extra (B,12)); see compute_extra_data
+        self.extra_features_fn = None      # optional override: callable(z_t) -> (X_extra (B,n,8), y_extra (B,12)); see compute_extra_data
+        self._extra_calc = None
         self.pos_encodings_fn = None       # callable(z_t) -> (B,n,dx); positional encodings are an input
         node_idx, edge_idx = graph.get_index_from_states(self.dataset_info.atom_decoder, self.dataset_info.bond_decoder,
                                                          list(cfg.diffusion.node_states_to_mask),
@@ -95,12 +96,19 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
     def get_pos_encodings_if_relevant(self, z_t):
         return self.get_pos_encodings(z_t)
 
-    def compute_extra_data(self, noisy_data):
-        """diffusion_abstract.py:350-372: concatenate the 8 node / 12 global extra features.  Computing them on the device
-        is SURVEY §8 f-1 ('next'); until then they come from `extra_features_fn` (inputs at the nn.Module boundary)."""
-        if self.extra_features_fn is None:
-            raise NotImplementedError('cfg.neuralnet.extra_features=True needs model.extra_features_fn (SURVEY §8 f-1)')
-        X_extra, y_extra = self.extra_features_fn(noisy_data)
+    def compute_extra_data(self, noisy_data, pad_noise=None):
+        """diffusion_abstract.py:350-372: concatenate the 8 node / 12 global extra features (ExtraFeatures('all') +
+        ExtraMolecularFeatures).  Computed on the device (diffalign_amd/extra_features.py); the reference
+        moves E, X and node_mask to the CPU for this at every step.  `extra_features_fn` (callable(z_t) -> (X_extra, y_extra))
+        overrides the built-in calculators, e.g. to feed precomputed features."""
+        if self.extra_features_fn is not None:
+            X_extra, y_extra = self.extra_features_fn(noisy_data)
+        else:
+            from . import extra_features as XF
+            if self._extra_calc is None:
+                self._extra_calc = (XF.ExtraFeatures('all', self.dataset_info), XF.ExtraMolecularFeatures(self.dataset_info))
+            X_extra, y_extra = XF.compute_extra_features(noisy_data.X, noisy_data.E, noisy_data.node_mask, *self._extra_calc,
+                                                         pad_noise=pad_noise)
         return noisy_data.get_new_object(X=torch.cat((noisy_data.X, X_extra), -1), y=torch.cat((noisy_data.y, y_extra), -1))
 
     def forward(self, z_t, use_pos_encoding_if_applicable=None, pos_encodings=None):

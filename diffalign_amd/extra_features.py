@@ -1,0 +1,147 @@
+"""Extra input features of the denoiser on the device.
+
+Host-side mirror of the reference's `ExtraFeatures` (neuralnet/extra_features.py:22-72) and `ExtraMolecularFeatures`
+(neuralnet/extra_features_molecular.py:6-26): same constructor arguments, same `forward` signatures and return
+tuples.  The reference moves E, X and node_mask to the CPU at every step (diffusion_abstract.py:361-364); here everything
+stays on the device: HIP kernels (csrc/k_extra.hip) for the passes over the edge state and the per-graph reductions,
+`torch.bmm` for the two adjacency powers and `torch.linalg.eigh` (fp64, like the reference) for the Laplacian.
+
+Requires a symmetric E (every diffusion state is: helpers.py:743-745) -- the cycle formulas use A = A^T.
+The eigenvector features (not-in-largest-component flag, two lowest non-trivial eigenvectors) depend on the basis the
+eigensolver returns inside degenerate eigenspaces, in the reference as here; eigenvalue features do not."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def _i(v):
+    return C.c_int(int(v))
+
+
+def _adjacency(E: torch.Tensor, nm_u8: torch.Tensor, bond_orders: torch.Tensor, want_L: bool):
+    B, n, _, ke = E.shape
+    dev = E.device
+    A = torch.empty(B, n, n, device=dev)
+    Lap = torch.empty(B, n, n, dtype=torch.float64, device=dev) if want_L else None
+    vw = torch.empty(B, n, device=dev); vp = torch.empty(B, n, device=dev)
+    L.check(L.lib().da_extra_adjacency(L.ptr(E, torch.float32), L.ptr(nm_u8), L.ptr(bond_orders, torch.float32), L.ptr(A), L.ptr(Lap),
+                                       L.ptr(vw), L.ptr(vp), _i(B), _i(n), _i(ke), L.stream()), 'da_extra_adjacency')
+    return A, Lap, vw, vp
+
+
+def _cycles(A: torch.Tensor, nm_u8: torch.Tensor):
+    B, n, _ = A.shape
+    k2 = torch.bmm(A, A)
+    k3 = torch.bmm(k2, A)
+    x = torch.empty(B, n, 3, device=A.device); y = torch.empty(B, 4, device=A.device)
+    L.check(L.lib().da_extra_cycles(L.ptr(A), L.ptr(k2), L.ptr(k3), L.ptr(nm_u8), L.ptr(x), L.ptr(y), _i(B), _i(n), L.stream()),
+            'da_extra_cycles')
+    return x, y
+
+
+def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Tensor]):
+    B, n, _ = Lap.shape
+    dev = Lap.device
+    evals, evecs = torch.linalg.eigh(Lap)                     # extra_features.py:118 (fp64)
+    evals = evals.contiguous()
+    if pad_noise is None:
+        pad_noise = torch.randn(B, n, device=dev)             # :189 (only keeps 0 from becoming the mode on padded slots)
+    s = evecs.stride()
+    assert s[0] == n * n, 'eigenvector batch is not dense'
+    ncomp = torch.empty(B, device=dev); ev5 = torch.empty(B, 5, device=dev)
+    nonlcc = torch.empty(B, n, device=dev); vec2 = torch.empty(B, n, 2, device=dev)
+    if not evecs.is_cuda:
+        raise L.DiffAlignHipError('diffalign_amd ops need tensors on a HIP device (no CPU fallback)')
+    L.check(L.lib().da_extra_eigen(L.ptr(evals, torch.float64), C.c_void_p(evecs.data_ptr()), C.c_longlong(s[1]), C.c_longlong(s[2]),
+                                   L.ptr(nm_u8), L.ptr(pad_noise.contiguous(), torch.float32), L.ptr(ncomp), L.ptr(ev5), L.ptr(nonlcc),
+                                   L.ptr(vec2), _i(B), _i(n), L.stream()), 'da_extra_eigen')
+    return ncomp, ev5, nonlcc, vec2
+
+
+class ExtraFeatures(nn.Module):
+    """neuralnet/extra_features.py:22-72.  forward(E, node_mask) -> (X_res, E_res, y_res)."""
+
+    def __init__(self, extra_features_type, dataset_info):
+        super().__init__()
+        if extra_features_type not in ('cycles', 'eigenvalues', 'all'):
+            raise ValueError(f'Features type {extra_features_type} not implemented')
+        self.max_n_nodes = dataset_info.max_n_nodes
+        self.features_type = extra_features_type
+
+    def forward(self, E, node_mask, pad_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        B, n = node_mask.shape
+        dev = E.device
+        E = E.contiguous().float()
+        nm_u8 = L.as_u8(node_mask)
+        zeros = torch.zeros(E.shape[-1], device=dev)          # the valency sums are not needed here
+        A, Lap, _, _ = _adjacency(E, nm_u8, zeros, self.features_type != 'cycles')
+        x_cycles, y_cycles = _cycles(A, nm_u8)
+        n_frac = node_mask.sum(dim=1, keepdim=True).float() / self.max_n_nodes
+        E_res = torch.zeros((*E.shape[:-1], 0), device=dev, dtype=E.dtype)
+        if self.features_type == 'cycles':
+            return x_cycles, E_res, torch.hstack((n_frac, y_cycles))
+        ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise)
+        y_res = torch.hstack((n_frac, y_cycles, ncomp.unsqueeze(-1), ev5))
+        if self.features_type == 'eigenvalues':
+            return x_cycles, E_res, y_res
+        return torch.cat((x_cycles, nonlcc.unsqueeze(-1), vec2), dim=-1), E_res, y_res
+
+
+class ExtraMolecularFeatures(nn.Module):
+    """neuralnet/extra_features_molecular.py:6-26.  forward(X, E) -> (X_res (B,n,2): charge, valency; E_res; y_res (B,1): weight)."""
+
+    def __init__(self, dataset_infos):
+        super().__init__()
+        self.valencies = [float(v) for v in dataset_infos.valencies]
+        self.bond_orders = [float(v) for v in dataset_infos.bond_orders]
+        self.atom_weight_list = [float(v) for v in dataset_infos.atom_weights.values()]
+        self.max_weight = float(dataset_infos.max_weight)
+        self._consts = {}
+
+    def consts(self, dev):
+        if dev not in self._consts:
+            self._consts[dev] = tuple(torch.tensor(v, dtype=torch.float32, device=dev)
+                                      for v in (self.valencies, self.bond_orders, self.atom_weight_list))
+        return self._consts[dev]
+
+    def from_valency_sums(self, X, vw, vp):
+        B, n, kx = X.shape
+        val, _, aw = self.consts(X.device)
+        assert val.numel() == kx and aw.numel() == kx, 'dataset_info.valencies / atom_weights do not match the node classes'
+        cv = torch.empty(B, n, 2, device=X.device); w = torch.empty(B, device=X.device)
+        L.check(L.lib().da_extra_molecular(L.ptr(X.contiguous().float(), torch.float32), L.ptr(val), L.ptr(aw), L.ptr(vw), L.ptr(vp),
+                                           C.c_float(self.max_weight), L.ptr(cv), L.ptr(w), _i(B), _i(n), _i(kx), L.stream()),
+                'da_extra_molecular')
+        return cv, w.unsqueeze(-1)
+
+    def forward(self, X, E):
+        B, n = X.shape[:2]
+        E = E.contiguous().float()
+        nm_u8 = torch.ones(B, n, dtype=torch.uint8, device=X.device)
+        _, _, vw, vp = _adjacency(E, nm_u8, self.consts(X.device)[1], False)
+        cv, w = self.from_valency_sums(X, vw, vp)
+        return cv, torch.zeros((*E.shape[:-1], 0), device=E.device, dtype=E.dtype), w
+
+
+def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: ExtraMolecularFeatures,
+                           pad_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The two calculators of diffusion_abstract.py:350-372 with ONE pass over the edge state.
+    Returns (X_extra (B,n,8), y_extra (B,12)) in the reference's concatenation order (features_type 'all')."""
+    assert extra.features_type == 'all'
+    dev = E.device
+    E = E.contiguous().float()
+    nm_u8 = L.as_u8(node_mask)
+    A, Lap, vw, vp = _adjacency(E, nm_u8, molecular.consts(dev)[1], True)
+    x_cycles, y_cycles = _cycles(A, nm_u8)
+    ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise)
+    cv, w = molecular.from_valency_sums(X, vw, vp)
+    n_frac = node_mask.sum(dim=1, keepdim=True).float() / extra.max_n_nodes
+    X_extra = torch.cat((x_cycles, nonlcc.unsqueeze(-1), vec2, cv), dim=-1)
+    y_extra = torch.hstack((n_frac, y_cycles, ncomp.unsqueeze(-1), ev5, w))
+    return X_extra, y_extra

@@ -199,6 +199,38 @@ int da_edge_out_g(const void* E_h, const void* blob, float* G, int B, int n, int
 int da_edge_out_finish(const float* G, const float* E_in, int de_in, const int* src, const float* skip1, const float* skip2,
                        float* E_logits, int B, int n, int ke, void* stream);
 
+/* ---- extra input features of the denoiser (reference: CPU round trip at every step,
+ * diffusion/diffusion_abstract.py:350-372).  The two adjacency powers and the batched symmetric eigendecomposition between
+ * these calls are library routines (torch.bmm, torch.linalg.eigh on the device; diffalign_amd/extra_features.py). ---- */
+
+/* One pass over the one-hot edge state E (B,n,n,ke) fp32: A = sum of the non-'none' channels (neuralnet/
+ * extra_features.py:81), the fp64 combinatorial Laplacian of the masked graph with 2n on the padded diagonal (:103-109,
+ * :133-146; L may be NULL), and per node the sums over j of argmax_c(E_ijc * bond_orders_c) and of argmax_c(E_ijc)
+ * (neuralnet/extra_features_molecular.py:40-42, :57-59). */
+int da_extra_adjacency(const float* E, const uint8_t* node_mask, const float* bond_orders, float* A, double* L,
+                       float* val_weighted, float* val_plain, int B, int n, int ke, void* stream);
+
+/* k-cycle counts per node (k = 3,4,5; /10, clipped at 1, masked) and per graph (k = 3..6) from A, K2 = A@A, K3 = K2@A
+ * (extra_features.py:75-90, :227-298).  A must be symmetric (every diffusion state is): diag(A^4), diag(A^5) and
+ * tr(A^6) are formed from K2 and K3. */
+int da_extra_cycles(const float* A, const float* K2, const float* K3, const uint8_t* node_mask, float* x_cycles /*(B,n,3)*/,
+                    float* y_cycles /*(B,4)*/, int B, int n, void* stream);
+
+/* Eigen-features from the ascending eigenvalues (B,n) and eigenvectors (element (i,k) of graph b at
+ * b*n*n + i*ld_row + k*ld_col) of the Laplacian (extra_features.py:117-128, :158-204): number of (near-)zero
+ * eigenvalues of L / n_real, the 5 next eigenvalues (2 beyond the spectrum), the not-in-largest-component indicator
+ * (mode of the first eigenvector rounded to 3 decimals; pad_noise (B,n) stands for the reference's randn on padded
+ * slots) and the 2 eigenvectors after the zero ones. */
+int da_extra_eigen(const double* evals, const double* evecs, long long ld_row, long long ld_col, const uint8_t* node_mask,
+                   const float* pad_noise, float* n_comp /*(B)*/, float* ev5 /*(B,5)*/, float* nonlcc /*(B,n)*/,
+                   float* vec2 /*(B,n,2)*/, int B, int n, void* stream);
+
+/* charge = argmax_c(X_c * valencies_c) - val_weighted, valency = val_plain, weight = sum_i atom_weights[argmax X_i] /
+ * max_weight (extra_features_molecular.py:29-72; the argmax INDEX is used, as in the reference). */
+int da_extra_molecular(const float* X, const float* valencies, const float* atom_weights, const float* val_weighted,
+                       const float* val_plain, float max_weight, float* charge_val /*(B,n,2)*/, float* weight /*(B)*/,
+                       int B, int n, int kx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -552,3 +552,82 @@ def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tenso
         c += 2
         _, _, zX, zE = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
     return zX, zE
+
+
+# --------------------------------------------------------------------------------------
+# a8  extra input features (cycle counts, Laplacian eigen-features, charge / valency / weight)
+# --------------------------------------------------------------------------------------
+def cycle_features(E: Tensor, node_mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """neuralnet/extra_features.py:75-90 (NodeCycleFeatures) + :227-298 (KNodeCycles): k-cycle counts per node
+    (k = 3, 4, 5) and per graph (k = 3..6) from the powers of A = sum of the non-'none' edge channels."""
+    A = E[..., 1:].sum(dim=-1).float()
+    d = A.sum(dim=-1)
+    k2 = A @ A; k3 = k2 @ A; k4 = k3 @ A; k5 = k4 @ A; k6 = k5 @ A                         # :234-242
+    dg = lambda M: torch.diagonal(M, dim1=-2, dim2=-1)
+    c3 = dg(k3)                                                                            # :244-247
+    c4 = dg(k4) - d * (d - 1) - (A @ d.unsqueeze(-1)).sum(dim=-1)                          # :249-252
+    tri = dg(k3)
+    c5 = dg(k5) - 2 * tri * d - (A @ tri.unsqueeze(-1)).sum(dim=-1) + tri                  # :254-259
+    c6 = (dg(k6).sum(-1) - 3 * dg(k3 ** 2).sum(-1) + 9 * (A * k2.pow(2)).sum(dim=[-2, -1])  # :261-277
+          - 6 * (dg(k2) * dg(k4)).sum(-1) + 6 * dg(k4).sum(-1) - 4 * dg(k3).sum(-1) + 4 * dg(k2).pow(3).sum(-1)
+          + 3 * k3.sum(dim=[-2, -1]) - 12 * dg(k2).pow(2).sum(-1) + 4 * dg(k2).sum(-1))
+    x = torch.stack([c3 / 2, c4 / 2, c5 / 2], dim=-1).float()
+    y = torch.stack([c3.sum(-1) / 6, c4.sum(-1) / 8, c5.sum(-1) / 10, c6 / 12], dim=-1).float()
+    x = x * node_mask.unsqueeze(-1) / 10                                                   # :84-89
+    y = y / 10
+    return x.clamp(max=1), y.clamp(max=1)
+
+
+def eigen_features(E: Tensor, node_mask: Tensor, pad_noise: Tensor):
+    """neuralnet/extra_features.py:102-128 (EigenFeatures, mode 'all'), :133-146 (combinatorial Laplacian), :158-174
+    (eigenvalue features) and :177-204 (eigenvector features).  `pad_noise` (B,n) replaces the reference's torch.randn on
+    the padded slots (:189).  fp64, torch.linalg.eigh, as the reference."""
+    mask = node_mask
+    A = E.double()[..., 1:].sum(dim=-1) * mask.unsqueeze(1) * mask.unsqueeze(2)
+    comb = torch.diag_embed(A.sum(dim=-1)) - A
+    Lap = (comb + comb.transpose(1, 2)) / 2
+    n = Lap.shape[-1]
+    mask_diag = 2 * n * torch.eye(n, dtype=Lap.dtype).unsqueeze(0) * (~mask.unsqueeze(1)) * (~mask.unsqueeze(2))
+    Lap = Lap * mask.unsqueeze(1) * mask.unsqueeze(2) + mask_diag
+    evals, evecs = torch.linalg.eigh(Lap)
+    evals = evals / mask.sum(dim=1, keepdim=True)
+    evecs = evecs * mask.unsqueeze(2) * mask.unsqueeze(1)
+    k = 5
+    ncomp = (evals < 1e-5).sum(dim=-1)                                                      # :166
+    ext = int(ncomp.max()) + k - n
+    ev = torch.hstack((evals, 2 * torch.ones(evals.shape[0], ext, dtype=evals.dtype))) if ext > 0 else evals
+    ev5 = torch.gather(ev, 1, torch.arange(k).unsqueeze(0) + ncomp.unsqueeze(1))           # :172-173
+    first = torch.round(evecs[:, :, 0], decimals=3) * mask + pad_noise.to(evecs.dtype) * (~mask)   # :187-190
+    mode = torch.mode(first, dim=1).values
+    nonlcc = ((first != mode.unsqueeze(1)) * mask).float()                                  # :192-193
+    ext = int(ncomp.max()) + 2 - n
+    V = torch.cat((evecs, torch.zeros(evecs.shape[0], n, ext, dtype=evecs.dtype)), dim=2) if ext > 0 else evecs
+    idx = (torch.arange(2).view(1, 1, 2) + ncomp.view(-1, 1, 1)).expand(-1, n, -1)
+    vec2 = torch.gather(V, 2, idx) * mask.unsqueeze(2)                                      # :199-202
+    return ncomp.float(), ev5.float(), nonlcc, vec2.float(), Lap
+
+
+def molecular_features(X: Tensor, E: Tensor, valencies, bond_orders, atom_weights, max_weight: float):
+    """neuralnet/extra_features_molecular.py:29-72: 'charge' (argmax index of X*valencies minus the sum of the argmax
+    indices of E*bond_orders), 'valency' (sum of the argmax indices of E) and molecular weight / max_weight."""
+    bo = torch.tensor(bond_orders, dtype=E.dtype).reshape(1, 1, 1, -1)
+    current = (E * bo).argmax(dim=-1).sum(dim=-1)                                           # :40-42
+    normal = (X * torch.tensor(valencies, dtype=X.dtype).reshape(1, 1, -1)).argmax(dim=-1)  # :44-46
+    charge = (normal - current).type_as(X)
+    valency = E.argmax(dim=-1).sum(dim=-1).type_as(X)                                       # :59-60
+    w = torch.tensor(list(atom_weights), dtype=torch.float32)[X.argmax(dim=-1)].sum(dim=-1, keepdim=True).type_as(X) / max_weight
+    return torch.stack((charge, valency), dim=-1), w
+
+
+def extra_features(X: Tensor, E: Tensor, node_mask: Tensor, max_n_nodes: int, valencies, bond_orders, atom_weights,
+                   max_weight: float, pad_noise: Tensor) -> Tuple[Tensor, Tensor]:
+    """diffusion/diffusion_abstract.py:350-372 with ExtraFeatures('all') (extra_features.py:31-33, :56-67): the 8 extra
+    node features [3 cycle counts, not-in-largest-component, 2 eigenvectors, charge, valency] and the 12 extra global
+    features [n / max_n, 4 cycle counts, #components, 5 eigenvalues, weight]."""
+    xc, yc = cycle_features(E, node_mask)
+    ncomp, ev5, nonlcc, vec2, _ = eigen_features(E, node_mask, pad_noise)
+    cv, w = molecular_features(X, E, valencies, bond_orders, atom_weights, max_weight)
+    n_frac = node_mask.sum(dim=1).unsqueeze(1) / max_n_nodes
+    X_extra = torch.cat((xc, nonlcc.unsqueeze(-1), vec2, cv), dim=-1)
+    y_extra = torch.hstack((n_frac, yc, ncomp.unsqueeze(-1), ev5, w))
+    return X_extra, y_extra

@@ -51,3 +51,81 @@ def load(name):
 
 def weights_of(z):
     return {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('w::')}
+
+
+def extra_info(ns):
+    """dataset_info fields the extra-feature calculators read (datasets/supernode_dataset.py:185-240: valencies and atomic
+    weights per node class with 0 for the first and last class, bond_orders [0,1,2,3,0,0,0], max_weight 390)."""
+    kx = len(ATOMS)
+    valencies = [0] + [(3 * i) % 5 + 1 for i in range(1, kx - 1)] + [0]
+    weights = [0.0] + [round(10.811 + 3.37 * i, 3) for i in range(1, kx - 1)] + [0.0]
+    return ns(max_n_nodes=300, valencies=valencies, bond_orders=[0, 1, 2, 3, 0, 0, 0], remove_h=False,
+              atom_weights={a: w for a, w in zip(ATOMS, weights)}, max_weight=390)
+
+
+def extra_case(z, name):
+    """(X one-hot, E one-hot, node_mask, pad_noise, X_extra, y_extra) of one case of extra_features.npz."""
+    import torch.nn.functional as F
+    kx, ke = len(ATOMS), len(BONDS)
+    X = F.one_hot(torch.from_numpy(z[f'{name}::X']).long(), kx).float()
+    X[torch.from_numpy(z[f'{name}::Xzero'])] = 0
+    E = F.one_hot(torch.from_numpy(z[f'{name}::E']).long(), ke).float()
+    E[torch.from_numpy(z[f'{name}::Ezero'])] = 0
+    g = lambda k: torch.from_numpy(z[f'{name}::{k}'])
+    return X, E, g('node_mask'), g('pad_noise'), g('X_extra'), g('y_extra')
+
+
+def components(E_onehot, node_mask):
+    """Connected-component label per node (min node index of its component; -1 on padding), from A = sum E[...,1:]."""
+    A = (E_onehot[..., 1:].sum(-1) > 0) & node_mask[:, :, None] & node_mask[:, None, :]
+    B, n = node_mask.shape
+    lab = torch.arange(n).repeat(B, 1)
+    for _ in range(n):
+        nb = torch.where(A, lab[:, None, :].expand(B, n, n), torch.full((B, n, n), n)).min(-1).values
+        new = torch.minimum(lab, nb)
+        if torch.equal(new, lab):
+            break
+        lab = new
+    return torch.where(node_mask, lab, torch.full_like(lab, -1))
+
+
+EXTRA_CASES = ('rxn_true', 'rxn_t5', 'conn', 'dense', 'sparse')
+
+
+def check_extra(X_extra, y_extra, case, z, E, node_mask, Lap=None, atol=2e-5):
+    """Compare (X_extra (B,n,8), y_extra (B,12)) with the golden outputs of the reference.  Cycle counts, eigenvalue
+    features, charge / valency / weight: direct.  Eigenvector features: only what does not depend on the eigensolver's
+    basis -- connected cases ('conn', 'dense'): nonlcc == golden (zeros) and vec2 == golden up to a sign per column
+    (simple eigenvalues); any case: nonlcc is 0 on padding and constant on every connected component; and, when the
+    Laplacian is given, each vec2 column is an eigenvector of it for the eigenvalue the y features report."""
+    gX, gy = torch.from_numpy(z[f'{case}::X_extra']), torch.from_numpy(z[f'{case}::y_extra'])
+    X_extra, y_extra = X_extra.detach().cpu().float(), y_extra.detach().cpu().float()
+    assert X_extra.shape == gX.shape and y_extra.shape == gy.shape
+    torch.testing.assert_close(X_extra[..., :3], gX[..., :3], atol=atol, rtol=1e-5)      # node cycle counts
+    torch.testing.assert_close(X_extra[..., 6:], gX[..., 6:], atol=0, rtol=0)            # charge, valency (integers)
+    torch.testing.assert_close(y_extra, gy, atol=atol, rtol=1e-5)                        # n, cycles, #comp, eigenvalues, weight
+    nonlcc, vec2 = X_extra[..., 3], X_extra[..., 4:6]
+    assert (nonlcc[~node_mask] == 0).all() and (vec2[~node_mask] == 0).all()
+    lab = components(E, node_mask)
+    for b in range(lab.shape[0]):
+        for c in lab[b].unique():
+            if c >= 0:
+                assert nonlcc[b][lab[b] == c].unique().numel() == 1, 'nonlcc differs inside a connected component'
+    if case in ('conn', 'dense'):
+        assert torch.equal(nonlcc, gX[..., 3])
+        for b in range(vec2.shape[0]):
+            for k in range(2):
+                v, gv = vec2[b, :, k], gX[b, :, 4 + k]
+                assert min((v - gv).abs().max(), (v + gv).abs().max()) <= 1e-4, (case, b, k)
+    if Lap is not None:
+        Lap = Lap.detach().cpu().double()
+        nreal = node_mask.sum(1)
+        for b in range(vec2.shape[0]):
+            ncomp = int(y_extra[b, 5])
+            for k in range(2):
+                if ncomp + k >= int(nreal[b]):
+                    continue
+                v = vec2[b, :, k].double()
+                lam = float(y_extra[b, 6 + k]) * float(nreal[b])
+                assert abs(float(v.norm()) - 1.0) <= 1e-4
+                assert float((Lap[b] @ v - lam * v).abs().max()) <= 1e-3 * max(1.0, lam), (case, b, k)

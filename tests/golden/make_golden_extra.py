@@ -1,0 +1,84 @@
+"""Golden vectors for the extra input features: the REFERENCE's ExtraFeatures('all') and
+ExtraMolecularFeatures run in the build container on seeded synthetic graphs.
+
+Run:  CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" python tests/golden/make_golden_extra.py
+(same stubbing of absent third-party modules as make_golden.py, which this script imports for it).
+
+The reference draws torch.randn for the padded slots of the first eigenvector (extra_features.py:189); the generator is
+seeded right before each call and the same draw is stored as `pad_noise`.  Outputs that depend on the eigensolver's basis
+inside degenerate eigenspaces (nonlcc, vec2) are stored too, but the tests compare them only through basis-independent
+properties; cases 'conn' are connected graphs with simple low eigenvalues, where they are defined up to a sign."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests.golden import make_golden as MG      # noqa: E402  (sets up the module stubs and sys.path)
+
+import torch                                     # noqa: E402
+import torch.nn.functional as F                  # noqa: E402
+from diffalign.neuralnet.extra_features import ExtraFeatures as RefExtra                       # noqa: E402
+from diffalign.neuralnet.extra_features_molecular import ExtraMolecularFeatures as RefMol      # noqa: E402
+from diffalign_amd import synthetic as S         # noqa: E402
+from tests.golden.common import ATOMS, BONDS, extra_info   # noqa: E402
+
+
+def random_graph(B, n, n_real, p, seed, connected):
+    """Symmetric one-hot (X, E, node_mask): G(n_real, p) plus, if `connected`, a Hamiltonian path."""
+    g = torch.Generator().manual_seed(seed)
+    kx, ke = len(ATOMS), len(BONDS)
+    X = torch.zeros(B, n, dtype=torch.long); E = torch.zeros(B, n, n, dtype=torch.long)
+    nm = torch.zeros(B, n, dtype=torch.bool)
+    for b in range(B):
+        r = n_real[b]
+        nm[b, :r] = True
+        X[b, :r] = torch.randint(1, kx - 1, (r,), generator=g)
+        u = torch.rand(r, r, generator=g) < p
+        cls = torch.randint(1, 4, (r, r), generator=g)
+        e = torch.triu(u * cls, 1)
+        if connected:
+            perm = torch.randperm(r, generator=g)
+            for k in range(1, r):
+                a, c = sorted((int(perm[k - 1]), int(perm[k])))
+                if e[a, c] == 0:
+                    e[a, c] = int(torch.randint(1, 4, (), generator=g))
+        E[b, :r, :r] = e + e.t()
+    Xo = F.one_hot(X, kx).float() * nm[:, :, None]
+    Eo = F.one_hot(E, ke).float() * (nm[:, :, None, None] & nm[:, None, :, None])
+    Eo[:, torch.eye(n, dtype=torch.bool)] = 0
+    return Xo, Eo, nm
+
+
+def run_case(name, X, E, nm, info, out, seed):
+    torch.manual_seed(seed)
+    pad_noise = torch.randn(nm.shape)                    # the draw extra_features.py:189 will make
+    torch.manual_seed(seed)
+    Xr, Er, yr = RefExtra('all', info)(E.clone(), nm.clone())
+    Xm, Em, ym = RefMol(info)(X.clone(), E.clone())
+    assert Er.shape[-1] == 0 and Em.shape[-1] == 0
+    out[f'{name}::X'] = X.argmax(-1) * nm; out[f'{name}::Xzero'] = X.sum(-1) == 0
+    out[f'{name}::E'] = E.argmax(-1).to(torch.uint8); out[f'{name}::Ezero'] = E.sum(-1) == 0
+    out[f'{name}::node_mask'] = nm; out[f'{name}::pad_noise'] = pad_noise
+    out[f'{name}::X_extra'] = torch.cat((Xr, Xm), -1); out[f'{name}::y_extra'] = torch.hstack((yr, ym))
+    print(name, tuple(Xr.shape), tuple(yr.shape), 'n_components', yr[:, 5].tolist())
+
+
+def main():
+    info = extra_info(MG.ns)
+    out = {}
+    true = S.make_reaction_batch(6, 48, seed=11)
+    run_case('rxn_true', true['X'], true['E'], true['node_mask'], info, out, 101)
+    z = S.noised_state(true, 5, 10, len(ATOMS) - 2, seed=12)
+    run_case('rxn_t5', z['X'], z['E'], z['node_mask'], info, out, 102)
+    X, E, nm = random_graph(4, 24, [24, 24, 17, 9], 0.12, 21, True)
+    run_case('conn', X, E, nm, info, out, 103)
+    X, E, nm = random_graph(3, 40, [40, 33, 40], 0.5, 22, False)
+    run_case('dense', X, E, nm, info, out, 104)
+    X, E, nm = random_graph(3, 70, [70, 64, 1], 0.03, 23, False)
+    run_case('sparse', X, E, nm, info, out, 105)
+    MG.save('extra_features', **out)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    main()

@@ -1,0 +1,101 @@
+"""GPU: extra input features on the device (csrc/k_extra.hip through the C-ABI + torch.bmm / torch.linalg.eigh) against the
+reference's outputs (tests/golden/extra_features.npz) and the CPU oracle.  Tolerance: cycle counts / eigenvalue features
+2e-5 absolute (fp32 features of fp64 eigenvalues), charge / valency exact; the eigenvector features are compared through
+basis-independent properties only (see tests/golden/common.py:check_extra)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.golden.common import load, extra_info, extra_case, check_extra, EXTRA_CASES, ATOMS
+
+pytestmark = pytest.mark.gpu
+D = torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('case', EXTRA_CASES)
+def test_extra_features_vs_reference_golden(case):
+    from diffalign_amd import extra_features as XF
+    z = load('extra_features')
+    info = extra_info(SimpleNamespace)
+    X, E, nm, pad_noise, _, _ = extra_case(z, case)
+    ef, mf = XF.ExtraFeatures('all', info), XF.ExtraMolecularFeatures(info)
+    Xe, ye = XF.compute_extra_features(X.to(D), E.to(D), nm.to(D), ef, mf, pad_noise=pad_noise.to(D))
+    torch.cuda.synchronize()
+    Lap = O.eigen_features(E, nm, pad_noise)[4]
+    check_extra(Xe, ye, case, z, E, nm, Lap)
+    # the two calculators on their own (the reference's class interface) give the same columns
+    Xr, Er, yr = ef(E.to(D), nm.to(D), pad_noise=pad_noise.to(D))
+    Xm, Em, ym = mf(X.to(D), E.to(D))
+    assert Er.shape == (*E.shape[:-1], 0) and Em.shape == (*E.shape[:-1], 0)
+    assert torch.equal(torch.cat((Xr, Xm), -1)[..., [0, 1, 2, 6, 7]], Xe[..., [0, 1, 2, 6, 7]])
+    assert torch.equal(torch.hstack((yr, ym))[:, :5], ye[:, :5]) and torch.equal(ym[:, 0], ye[:, 11])
+    # Laplacian written by the kernel == the oracle's, bit for bit (small integers in fp64)
+    _, Lk, _, _ = XF._adjacency(E.to(D), nm.to(D).view(torch.uint8), torch.zeros(E.shape[-1], device=D), True)
+    assert torch.equal(Lk.cpu(), Lap)
+
+
+def test_extra_features_cycles_modes_and_bench_size():
+    """'cycles' / 'eigenvalues' modes return the reference's column subsets; the benchmark's size (n = 300) against the
+    oracle on one graph."""
+    from diffalign_amd import extra_features as XF
+    from diffalign_amd import synthetic as S
+    info = extra_info(SimpleNamespace)
+    true = S.make_reaction_batch(2, 300, seed=5, P=142)
+    z = S.noised_state(true, 250, 500, len(ATOMS) - 2, seed=6)
+    X, E, nm = z['X'], z['E'], z['node_mask']
+    pad_noise = torch.randn(nm.shape, generator=torch.Generator().manual_seed(1))
+    Xo, yo = O.extra_features(X, E, nm, info.max_n_nodes, info.valencies, info.bond_orders, info.atom_weights.values(), info.max_weight,
+                              pad_noise)
+    ef, mf = XF.ExtraFeatures('all', info), XF.ExtraMolecularFeatures(info)
+    Xe, ye = XF.compute_extra_features(X.to(D), E.to(D), nm.to(D), ef, mf, pad_noise=pad_noise.to(D))
+    torch.testing.assert_close(Xe.cpu()[..., :3], Xo[..., :3], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(Xe.cpu()[..., 6:], Xo[..., 6:], atol=0, rtol=0)
+    torch.testing.assert_close(ye.cpu(), yo, atol=2e-5, rtol=1e-5)
+    xc, Ec, yc = XF.ExtraFeatures('cycles', info)(E.to(D), nm.to(D))
+    assert xc.shape == (2, 300, 3) and yc.shape == (2, 5) and torch.equal(yc, ye[:, :5]) and torch.equal(xc, Xe[..., :3])
+    xv, Ev, yv = XF.ExtraFeatures('eigenvalues', info)(E.to(D), nm.to(D))
+    assert yv.shape == (2, 11) and torch.equal(yv, ye[:, :11])
+
+
+def test_model_forward_and_sampling_with_extra_features():
+    """cfg.neuralnet.extra_features=True: DiscreteDenoisingDiffusion computes the features itself on the device (no
+    extra_features_fn, no host round trip): X grows by 8 columns, y by 12; the logits equal the CPU oracle's denoiser fed the
+    same features (rel-L2 <= 2e-2); a short reverse chain runs end to end and returns valid symmetric one-hot graphs."""
+    from types import SimpleNamespace as ns
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    from tests.golden.common import tiny_dims, init_state_dict, BONDS
+    from tests.test_gpu_sampling import make_cfg, make_info
+    info = make_info()
+    for k, v in vars(extra_info(ns)).items():
+        setattr(info, k, v)
+    dims = tiny_dims()
+    model = DiscreteDenoisingDiffusion(make_cfg(dims, extra=True), info, device='cuda:0').eval()
+    sd = init_state_dict({k: v.shape for k, v in model.model.state_dict().items()}, 5)
+    model.model.load_state_dict(sd)
+    assert sd['mlp_in_X.0.weight'].shape[1] == len(ATOMS) + 8 and sd['mlp_in_y.0.weight'].shape[1] == 1 + 12
+    true = S.make_reaction_batch(3, 40, seed=9)
+    z = S.noised_state(true, 5, 10, len(ATOMS) - 2, seed=10)
+    pos = S.shared_pos_encodings(true, dims['hidden_dims']['dx'], seed=4)
+    model.pos_encodings_fn = lambda zt: pos.to(D)
+    zt = PlaceHolder(X=z['X'].to(D), E=z['E'].to(D), y=z['y'].to(D), node_mask=z['node_mask'].to(D),
+                     atom_map_numbers=z['atom_map_numbers'].to(D), mol_assignments=z['mol_assignments'].to(D))
+    pn = torch.randn(3, 40, generator=torch.Generator().manual_seed(2)).to(D)
+    ext = model.compute_extra_data(zt, pad_noise=pn)
+    assert ext.X.shape[-1] == len(ATOMS) + 8 and ext.y.shape[-1] == 13
+    model.extra_features_fn = lambda zz: (ext.X[..., len(ATOMS):], ext.y[..., 1:])      # same features, fed by hand
+    with torch.no_grad():
+        pred = model.forward(zt, pos_encodings=pos.to(D))
+    oX, oE, _ = O.denoiser_forward(sd, ext.X.cpu(), ext.E.cpu(), ext.y.cpu(), z['node_mask'], dims['n_layers'], dims['hidden_dims']['n_head'],
+                                   (len(ATOMS), len(BONDS), 1), atom_map_numbers=z['atom_map_numbers'], pos_encodings=pos,
+                                   mol_assignments=z['mol_assignments'], p_to_r_skip_connection=True)
+    rel = lambda a, b: ((a.cpu().double() - b.double()).norm() / b.double().norm()).item()
+    assert rel(pred.X, oX) <= 2e-2 and rel(pred.E, oE) <= 2e-2, (rel(pred.X, oX), rel(pred.E, oE))
+    model.extra_features_fn = None                                                    # built-in path inside the loop
+    data = PlaceHolder(X=true['X'].to(D), E=true['E'].to(D), y=torch.zeros(3, 1, device=D), node_mask=true['node_mask'].to(D),
+                       atom_map_numbers=true['atom_map_numbers'].to(D), mol_assignments=true['mol_assignments'].to(D))
+    out = model.sample_one_batch(data=data)
+    assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())

@@ -182,3 +182,19 @@ def test_single_step_logits_and_chain_config0():
     assert int(z['chain_noise_calls']) == 22
     assert np.array_equal(zX.argmax(-1).numpy(), z['chain_X'])
     assert np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
+
+
+@pytest.mark.parametrize('case', ['rxn_true', 'rxn_t5', 'conn', 'dense', 'sparse'])
+def test_extra_features(case):
+    """a8: oracle restatement of ExtraFeatures('all') + ExtraMolecularFeatures vs the reference's outputs."""
+    from types import SimpleNamespace
+    from tests.golden.common import extra_info, extra_case, check_extra
+    z = load('extra_features')
+    info = extra_info(SimpleNamespace)
+    X, E, nm, pad_noise, _, _ = extra_case(z, case)
+    Xe, ye = O.extra_features(X, E, nm, info.max_n_nodes, info.valencies, info.bond_orders, info.atom_weights.values(),
+                              info.max_weight, pad_noise)
+    Lap = O.eigen_features(E, nm, pad_noise)[4]
+    check_extra(Xe, ye, case, z, E, nm, Lap)
+    # same LAPACK as the generator: the basis-dependent outputs agree too
+    torch.testing.assert_close(Xe, torch.from_numpy(z[f'{case}::X_extra']), atol=2e-5, rtol=1e-5)
