@@ -36,7 +36,8 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
         self.device_ = torch.device(device)
         self.extra_features_fn = None      # optional override: callable(z_t) -> (X_extra (B,n,8), y_extra (B,12)); see compute_extra_data
         self._extra_calc = None
-        self.pos_encodings_fn = None       # callable(z_t) -> (B,n,dx); positional encodings are an input
+        self.pos_encodings_fn = None       # optional override: callable(z_t) -> (B,n,dx); see get_pos_encodings
+        self.pos_emb_module = None
         node_idx, edge_idx = graph.get_index_from_states(self.dataset_info.atom_decoder, self.dataset_info.bond_decoder,
                                                          list(cfg.diffusion.node_states_to_mask),
                                                          cfg.diffusion.edge_states_to_mask)
@@ -86,12 +87,26 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
         return z_t, prob_t
 
     def get_pos_encodings(self, z_t):
+        """diffusion_abstract.py:266-284: positional encodings by cfg.neuralnet.pos_encoding_type, computed on the device
+        (diffalign_amd/pos_encodings.py).  `pos_encodings_fn` (callable(z_t) -> (B,n,dx)) overrides them."""
         if self.cfg.neuralnet.architecture != 'with_y_atommap_number_pos_enc':
             return None
-        if self.pos_encodings_fn is None:
-            raise NotImplementedError(f"positional encodings ('{self.cfg.neuralnet.pos_encoding_type}') are an input at this "
-                                      'boundary (SURVEY §8 a13 / f-3): set model.pos_encodings_fn or pass pos_encodings')
-        return self.pos_encodings_fn(z_t)
+        if self.pos_encodings_fn is not None:
+            return self.pos_encodings_fn(z_t)
+        if self.pos_emb_module is None:
+            from .pos_encodings import PositionalEmbedding
+            self.pos_emb_module = PositionalEmbedding(self.cfg.neuralnet.hidden_dims['dx'], self.cfg.neuralnet.pos_emb_permutations)
+        kind, pe = self.cfg.neuralnet.pos_encoding_type, self.pos_emb_module
+        if kind == 'smiles_pos_enc':
+            return pe.matched_positional_encodings_sinusoidal(z_t.atom_map_numbers, z_t.mol_assignments, direction='retro')
+        if kind in ('laplacian_pos_enc', 'laplacian_pos_enc_gpu'):
+            return pe.matched_positional_encodings_laplacian(z_t.E.argmax(-1), z_t.atom_map_numbers, z_t.mol_assignments,
+                                                             self.cfg.neuralnet.num_lap_eig_vectors, direction='retro')
+        if kind == 'infoleak_pos_enc':
+            return pe.matched_positional_encodings_infoleak(z_t.atom_map_numbers, z_t.mol_assignments, direction='retro')
+        if kind == 'gaussian_pos_enc':
+            return pe.matched_positional_encodings_gaussian(z_t.atom_map_numbers, z_t.mol_assignments)
+        raise ValueError(f'pos_encoding_type {kind} not recognized')
 
     def get_pos_encodings_if_relevant(self, z_t):
         return self.get_pos_encodings(z_t)

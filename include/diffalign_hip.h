@@ -231,6 +231,26 @@ int da_extra_molecular(const float* X, const float* valencies, const float* atom
                        const float* val_plain, float max_weight, float* charge_val /*(B,n,2)*/, float* weight /*(B)*/,
                        int B, int n, int kx, void* stream);
 
+/* ---- positional encodings shared between mapped reactant / product atoms (reference: per-graph Python loops on
+ * the CPU, neuralnet/transformer_model_with_y.py:213-503 PositionalEmbedding) ---- */
+
+/* position (B,n): 1-based rank, inside the product (the molecule with the largest assignment), of the product node that
+ * carries the node's atom-map number, 0 if none (:400-412, :259-275; last product node wins on duplicates, as the
+ * reference's sequential scatter_); prod_node (B,n+1): node index of the k-th product node; n_prod (B). */
+int da_pos_product_index(const int64_t* atom_map_numbers, const int64_t* mol_assignments, int* position, int* prod_node,
+                         int* n_prod, int B, int n, void* stream);
+/* SinusoidalPosEmb (:114-131): out (rows,dim) = [sin(1000 v f_j), cos(1000 v f_j)], freq (dim/2) as torch computes it. */
+int da_pos_sinusoidal(const float* value, const float* freq, float* out, long long rows, int dim, void* stream);
+/* out[b,i,:] = table[b, idx[b,i], :]  (Gaussian encodings, :492-503, idx = atom-map number). */
+int da_pos_gather_rows(const float* table, const int64_t* idx, float* out, int B, int n, int rows_per_graph, int dim, void* stream);
+/* fp32 symmetric-normalised Laplacian (B,n,n) of the product block: unweighted edges where the bond class is non-zero and
+ * both ends are product nodes, L_ii = 1 everywhere (:147-154, :192-198). */
+int da_pos_laplacian(const int64_t* E_classes, const int64_t* mol_assignments, float* L, int B, int n, void* stream);
+/* out (B,n,dim): columns 1..k (k = min(max_eig, n_prod)) of the ascending eigenvectors, row of the product node at
+ * `position`, times sign (B,max_eig); zero elsewhere (:254-259, :275). */
+int da_pos_lap_gather(const float* evecs, long long ld_row, long long ld_col, const int* position, const int* prod_node,
+                      const int* n_prod, const float* sign, float* out, int B, int n, int dim, int max_eig, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

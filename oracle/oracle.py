@@ -631,3 +631,79 @@ def extra_features(X: Tensor, E: Tensor, node_mask: Tensor, max_n_nodes: int, va
     X_extra = torch.cat((xc, nonlcc.unsqueeze(-1), vec2, cv), dim=-1)
     y_extra = torch.hstack((n_frac, yc, ncomp.unsqueeze(-1), ev5, w))
     return X_extra, y_extra
+
+
+# --------------------------------------------------------------------------------------
+# a13  positional encodings shared between mapped reactant / product atoms
+# --------------------------------------------------------------------------------------
+def product_positions(atom_map_numbers: Tensor, mol_assignments: Tensor) -> Tensor:
+    """neuralnet/transformer_model_with_y.py:400-412 (and :259-275): for every node, the 1-based rank inside the product
+    (the molecule with the largest assignment index) of the product atom carrying the node's atom-map number; 0 if none.
+    The sequential scatter_ lets the last product atom win on duplicate numbers (0 included)."""
+    B, n = atom_map_numbers.shape
+    pos = torch.zeros_like(atom_map_numbers)
+    for b in range(B):
+        pidx = mol_assignments[b].max()
+        prod = (mol_assignments[b] == pidx).nonzero().squeeze(1)
+        table = torch.zeros(int(atom_map_numbers[b].max()) + 1, dtype=torch.long)
+        for k, node in enumerate(prod.tolist(), start=1):
+            table[int(atom_map_numbers[b, node])] = k
+        pos[b] = table[atom_map_numbers[b]]
+    return pos
+
+
+def sinusoidal_pos_emb(x: Tensor, dim: int) -> Tensor:
+    """neuralnet/transformer_model_with_y.py:114-131 (SinusoidalPosEmb)."""
+    x = x.reshape(-1).float() * 1000
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    emb = torch.exp(torch.arange(half) * -emb).type_as(x)
+    emb = x[:, None] * emb[None, :]
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+def pos_enc_sinusoidal(atom_map_numbers: Tensor, mol_assignments: Tensor, dim: int) -> Tensor:
+    """:389-417 matched_positional_encodings_sinusoidal, direction 'retro'."""
+    B, n = atom_map_numbers.shape
+    return sinusoidal_pos_emb(product_positions(atom_map_numbers, mol_assignments), dim).reshape(B, n, dim)
+
+
+def pos_enc_infoleak(atom_map_numbers: Tensor, dim: int) -> Tensor:
+    """:451-490 matched_positional_encodings_infoleak with pos_emb_permutations = 0."""
+    B, n = atom_map_numbers.shape
+    return sinusoidal_pos_emb(atom_map_numbers, dim).reshape(B, n, dim)
+
+
+def pos_enc_gaussian(atom_map_numbers: Tensor, noise: Tensor) -> Tensor:
+    """:492-503 matched_positional_encodings_gaussian; `noise` (B,n,dim) is the reference's torch.randn draw."""
+    noise = noise.clone()
+    noise[:, 0, :] = 0
+    return torch.stack([noise[b, atom_map_numbers[b]] for b in range(noise.shape[0])])
+
+
+def pos_enc_laplacian(E_classes: Tensor, atom_map_numbers: Tensor, mol_assignments: Tensor, max_eigenvectors: int, dim: int,
+                      signs: Tensor):
+    """:221-287 matched_positional_encodings_laplacian (retro) with the dense decomposition of laplacian_eigenvectors_gpu
+    (:173-211): product-block graph, unweighted symmetric-normalised Laplacian with unit diagonal (torch_geometric
+    get_laplacian(normalization='sym'), :150-154), eigenvectors 1..k of the ascending spectrum times `signs` (B,max_eig),
+    rows of the product shared through the atom-map numbers, zero padded to dim.
+    PARITY UNPINNED against the reference for this function: it needs torch_geometric (and scipy's ARPACK for the
+    non-GPU variant), absent from the container; tests check it through eigenvector properties instead."""
+    B, n = atom_map_numbers.shape
+    out = torch.zeros(B, n, dim)
+    pos = product_positions(atom_map_numbers, mol_assignments)
+    laps = []
+    for b in range(B):
+        isprod = mol_assignments[b] == mol_assignments[b].max()
+        A = ((E_classes[b] != 0) & isprod[:, None] & isprod[None, :]).float()
+        A.fill_diagonal_(0)
+        deg = A.sum(-1)
+        dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+        Lap = torch.eye(n) - dis[:, None] * A * dis[None, :]
+        laps.append(Lap)
+        _, vec = torch.linalg.eigh(Lap)
+        k = min(max_eigenvectors, int(isprod.sum()))
+        pe = vec[:, 1:k + 1] * signs[b, :k]
+        table = torch.cat([torch.zeros(1, dim), torch.cat([pe, torch.zeros(n, dim - k)], dim=-1)[isprod]], 0)
+        out[b] = table[pos[b]]
+    return out, torch.stack(laps)

@@ -63,7 +63,34 @@ def run_case(name, X, E, nm, info, out, seed):
     print(name, tuple(Xr.shape), tuple(yr.shape), 'n_components', yr[:, 5].tolist())
 
 
+def gen_pos_encodings():
+    """Deterministic positional-encoding variants of the reference's PositionalEmbedding (sinusoidal product index, info-leak,
+    Gaussian rows).  The Laplacian variants need torch_geometric (absent here): parity unpinned, see tests."""
+    from diffalign.neuralnet.transformer_model_with_y import PositionalEmbedding as RefPE
+    dim = 64
+    true = S.make_reaction_batch(5, 48, seed=31)
+    am, mol = true['atom_map_numbers'].clone(), true['mol_assignments'].clone()
+    am2 = am.clone()
+    prod = (mol[1] == mol[1].max()).nonzero().squeeze(1)
+    am2[1, prod[2]] = 0; am2[1, prod[5]] = 0            # two unmapped product atoms (the scatter_ of :410 then rewrites slot 0)
+    p2 = (mol[2] == mol[2].max()).nonzero().squeeze(1)
+    am2[2, p2[0]] = int(am2[2, p2[3]])                  # a duplicated number inside the product
+    pe = RefPE(dim, 0)
+    out = {'dim': dim}
+    for tag, a in (('a', am), ('b', am2)):
+        out[f'{tag}::am'] = a; out[f'{tag}::mol'] = mol
+        out[f'{tag}::sinusoidal'] = pe.matched_positional_encodings_sinusoidal(a.clone(), mol.clone(), direction='retro')
+        out[f'{tag}::infoleak'] = pe.matched_positional_encodings_infoleak(a.clone(), mol.clone(), direction='retro')
+        torch.manual_seed(77)
+        noise = torch.randn(a.shape[0], a.shape[1], dim)
+        torch.manual_seed(77)
+        out[f'{tag}::gaussian'] = pe.matched_positional_encodings_gaussian(a.clone(), mol.clone())
+        out[f'{tag}::gaussian_noise'] = noise
+    MG.save('pos_encodings', **out)
+
+
 def main():
+    gen_pos_encodings()
     info = extra_info(MG.ns)
     out = {}
     true = S.make_reaction_batch(6, 48, seed=11)

@@ -198,3 +198,15 @@ def test_extra_features(case):
     check_extra(Xe, ye, case, z, E, nm, Lap)
     # same LAPACK as the generator: the basis-dependent outputs agree too
     torch.testing.assert_close(Xe, torch.from_numpy(z[f'{case}::X_extra']), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_pos_encodings(tag):
+    """a13: sinusoidal product-index, info-leak and Gaussian positional encodings vs the reference's PositionalEmbedding
+    ('b' has unmapped and duplicated product atom-map numbers).  sin/cos of arguments up to 5e4: 1e-6 absolute."""
+    z = load('pos_encodings')
+    dim = int(z['dim'])
+    am, mol = torch.from_numpy(z[f'{tag}::am']), torch.from_numpy(z[f'{tag}::mol'])
+    torch.testing.assert_close(O.pos_enc_sinusoidal(am, mol, dim), torch.from_numpy(z[f'{tag}::sinusoidal']), atol=1e-6, rtol=0)
+    torch.testing.assert_close(O.pos_enc_infoleak(am, dim), torch.from_numpy(z[f'{tag}::infoleak']), atol=1e-6, rtol=0)
+    assert torch.equal(O.pos_enc_gaussian(am, torch.from_numpy(z[f'{tag}::gaussian_noise'])), torch.from_numpy(z[f'{tag}::gaussian']))
