@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from tests.golden import make_golden as MG      # noqa: E402  (sets up the module stubs and sys.path)
 
+import numpy as np                               # noqa: E402
 import torch                                     # noqa: E402
 import torch.nn.functional as F                  # noqa: E402
 from diffalign.neuralnet.extra_features import ExtraFeatures as RefExtra                       # noqa: E402
@@ -89,8 +90,34 @@ def gen_pos_encodings():
     MG.save('pos_encodings', **out)
 
 
+def gen_ranking():
+    """sort_by_elbo (diffusion_rxn.py:643-699) and reactions_sorted_with_weighted_prob (utils/graph.py:709-736) of the reference
+    on synthetic scores: 3 conditions x 5 samples, some duplicates dropped."""
+    import json
+    from diffalign.diffusion.diffusion_rxn import DiscreteDenoisingDiffusionRxn as RefRxn
+    from diffalign.utils import graph as ref_graph
+    g = torch.Generator().manual_seed(8)
+    bs, ns_ = 3, 5
+    elbos = torch.rand(bs * ns_, generator=g) * 40 + 5
+    loss_t = torch.rand(bs * ns_, generator=g) * 30
+    loss_0 = -torch.rand(bs * ns_, generator=g)
+    is_unique = [True, True, False, True, True, True, False, False, True, True, True, True, True, False, True]
+    counts = [1, 2, 1, 1, 3, 1, 1, 2, 1, 1, 1]                      # one per unique sample
+    u = [i for i, f in enumerate(is_unique) if f]
+    rct = [[f'R{i}a', f'R{i}b'] for i in u]
+    prod = [[f'P{i // ns_}'] for i in u]
+    # the reference indexes elbos with positions inside the unique list (its callers pass the scores of the unique samples)
+    eu, tu, zu = elbos[:len(u)], loss_t[:len(u)], loss_0[:len(u)]
+    res = RefRxn.sort_by_elbo(None, eu, tu, zu, rct, prod, is_unique, counts, bs, ns_)
+    ranked = ref_graph.reactions_sorted_with_weighted_prob(res, 0.3)
+    MG.save('ranking', elbos=eu, loss_t=tu, loss_0=zu, is_unique=torch.tensor(is_unique), counts=torch.tensor(counts), bs=bs, n_samples=ns_,
+            sorted_json=np.frombuffer(json.dumps(res, sort_keys=True).encode(), dtype=np.uint8),
+            ranked_json=np.frombuffer(json.dumps(ranked, sort_keys=True).encode(), dtype=np.uint8))
+
+
 def main():
     gen_pos_encodings()
+    gen_ranking()
     info = extra_info(MG.ns)
     out = {}
     true = S.make_reaction_batch(6, 48, seed=11)
