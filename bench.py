@@ -43,7 +43,11 @@ def make_cfg(dims, T=500, T_eval=100):
 
 def make_info():
     from diffalign_amd.synthetic import ATOM_DECODER, BOND_DECODER
-    return ns(atom_decoder=list(ATOM_DECODER), bond_decoder=list(BOND_DECODER),
+    kx = len(ATOM_DECODER)
+    # fields of the extra-feature calculators (datasets/supernode_dataset.py:185-240); synthetic valencies / weights
+    extra = dict(max_n_nodes=300, valencies=[0] + [(3 * i) % 5 + 1 for i in range(1, kx - 1)] + [0], bond_orders=[0, 1, 2, 3, 0, 0, 0],
+                 atom_weights={a: (0.0 if i in (0, kx - 1) else 10.811 + 3.37 * i) for i, a in enumerate(ATOM_DECODER)}, max_weight=390)
+    return ns(**extra, atom_decoder=list(ATOM_DECODER), bond_decoder=list(BOND_DECODER),
               input_dims={'X': len(ATOM_DECODER), 'E': len(BOND_DECODER), 'y': 1},
               output_dims={'X': len(ATOM_DECODER), 'E': len(BOND_DECODER), 'y': 0}, nodes_dist=None,
               node_types=torch.ones(len(ATOM_DECODER)), edge_types=torch.ones(len(BOND_DECODER)))
@@ -98,6 +102,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--nodes', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--extra-features', choices=['inputs', 'device'], default='inputs',
+                    help="'inputs' (default, SURVEY §8d: the 8 + 12 extra features are given); 'device': computed inside the step "
+                         '(csrc/k_extra.hip + torch.linalg.eigh), as a real sampling loop does')
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
@@ -128,7 +135,8 @@ def main():
     model.pos_encodings_fn = lambda z: pos
     g = torch.Generator().manual_seed(7)
     xe, ye = torch.rand(B, n, 8, generator=g).to(dev), torch.rand(B, 12, generator=g).to(dev)
-    model.extra_features_fn = lambda z: (xe, ye)               # extra features are inputs
+    if args.extra_features == 'inputs':
+        model.extra_features_fn = lambda z: (xe, ye)           # extra features are inputs
     kx, ke = data.X.shape[-1], data.E.shape[-1]
     T_eval = 100
     zt0 = S.noised_state(true, t=50, T=T_eval, abs_x=S.IDX_AU, seed=11 + rank)
@@ -210,6 +218,7 @@ def main():
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                'config': {'workload': f'align_absorbing denoiser forward + posterior/sample/mask, batch {B}/GPU padded to n={n} '
                                       '(BASELINE.json configs[1]), 9 layers, 8.18M params, random-init weights',
+                          'extra_features': 'given as inputs (SURVEY 8d)' if args.extra_features == 'inputs' else 'computed on the device inside the step',
                           'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)'},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:

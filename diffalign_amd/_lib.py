@@ -33,7 +33,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+# Tensors handed to ptr() since the last check(): a temporary built inside a call expression (`L.ptr(x.float())`) would
+# otherwise be freed as soon as ptr() returns, and the caching allocator could give its block to the NEXT temporary of the
+# same expression before the kernel has even been enqueued.  Once the entry point has returned (check()), stream order
+# protects the block.
+_held = []
+
+
 def check(rc: int, what: str) -> None:
+    _held.clear()
     if rc != 0:
         raise DiffAlignHipError(f'{what} failed (rc={rc}): {lib().da_last_error().decode()}')
 
@@ -48,6 +56,7 @@ def ptr(t: Optional[torch.Tensor], dtype=None) -> C.c_void_p:
         raise DiffAlignHipError('tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise DiffAlignHipError(f'expected dtype {dtype}, got {t.dtype}')
+    _held.append(t)
     return C.c_void_p(t.data_ptr())
 
 

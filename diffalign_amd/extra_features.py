@@ -12,6 +12,7 @@ eigensolver returns inside degenerate eigenspaces, in the reference as here; eig
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -45,21 +46,32 @@ def _cycles(A: torch.Tensor, nm_u8: torch.Tensor):
     return x, y
 
 
-def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Tensor]):
+# 'hip' (default): the one-launch batched partial eigensolver of csrc/k_extra_eig.hip; 'torch': torch.linalg.eigh (rocSOLVER
+# syevd, fp64, the reference's routine) followed by k_extra_eigen -- 4x slower at B = 64, n = 300, kept for cross-checks.
+EIGENSOLVER = os.environ.get('DA_EXTRA_EIGH', 'hip')
+
+
+def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Tensor], solver: Optional[str] = None):
+    """Eigen-features of the fp64 Laplacians (B,n,n) (extra_features.py:117-128, :158-204).  `Lap` is overwritten."""
     B, n, _ = Lap.shape
     dev = Lap.device
-    evals, evecs = torch.linalg.eigh(Lap)                     # extra_features.py:118 (fp64)
-    evals = evals.contiguous()
     if pad_noise is None:
         pad_noise = torch.randn(B, n, device=dev)             # :189 (only keeps 0 from becoming the mode on padded slots)
-    s = evecs.stride()
-    assert s[0] == n * n, 'eigenvector batch is not dense'
+    pad_noise = pad_noise.contiguous()
     ncomp = torch.empty(B, device=dev); ev5 = torch.empty(B, 5, device=dev)
     nonlcc = torch.empty(B, n, device=dev); vec2 = torch.empty(B, n, 2, device=dev)
+    if (solver or EIGENSOLVER) == 'hip' and n <= 1024:
+        L.check(L.lib().da_extra_eigen_solve(L.ptr(Lap, torch.float64), L.ptr(nm_u8), L.ptr(pad_noise, torch.float32), L.ptr(ncomp), L.ptr(ev5),
+                                             L.ptr(nonlcc), L.ptr(vec2), C.c_void_p(0), _i(B), _i(n), L.stream()), 'da_extra_eigen_solve')
+        return ncomp, ev5, nonlcc, vec2
+    evals, evecs = torch.linalg.eigh(Lap)                     # extra_features.py:118 (fp64)
+    evals = evals.contiguous()
+    s = evecs.stride()
+    assert s[0] == n * n, 'eigenvector batch is not dense'
     if not evecs.is_cuda:
         raise L.DiffAlignHipError('diffalign_amd ops need tensors on a HIP device (no CPU fallback)')
     L.check(L.lib().da_extra_eigen(L.ptr(evals, torch.float64), C.c_void_p(evecs.data_ptr()), C.c_longlong(s[1]), C.c_longlong(s[2]),
-                                   L.ptr(nm_u8), L.ptr(pad_noise.contiguous(), torch.float32), L.ptr(ncomp), L.ptr(ev5), L.ptr(nonlcc),
+                                   L.ptr(nm_u8), L.ptr(pad_noise, torch.float32), L.ptr(ncomp), L.ptr(ev5), L.ptr(nonlcc),
                                    L.ptr(vec2), _i(B), _i(n), L.stream()), 'da_extra_eigen')
     return ncomp, ev5, nonlcc, vec2
 

@@ -225,6 +225,14 @@ int da_extra_eigen(const double* evals, const double* evecs, long long ld_row, l
                    const float* pad_noise, float* n_comp /*(B)*/, float* ev5 /*(B,5)*/, float* nonlcc /*(B,n)*/,
                    float* vec2 /*(B,n,2)*/, int B, int n, void* stream);
 
+/* The same features as torch.linalg.eigh + da_extra_eigen, in one launch, one workgroup per graph: in-place Householder
+ * tridiagonalisation of L (B,n,n) fp64 (DESTROYED), Sturm count / bisection for the eigenvalues that are used (the count
+ * below 1e-5 * n_real, then 5), inverse iteration + back-transformation for eigenvectors 0, n_comp, n_comp + 1
+ * (extra_features.py:117-128, :158-204; no counterpart in the reference: it calls LAPACK for the full decomposition).
+ * evals6 (B,6), optional: eigenvalues 0 and n_comp .. n_comp+4 of L.  n <= 1024. */
+int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
+                         float* vec2, double* evals6, int B, int n, void* stream);
+
 /* charge = argmax_c(X_c * valencies_c) - val_weighted, valency = val_plain, weight = sum_i atom_weights[argmax X_i] /
  * max_weight (extra_features_molecular.py:29-72; the argmax INDEX is used, as in the reference). */
 int da_extra_molecular(const float* X, const float* valencies, const float* atom_weights, const float* val_weighted,

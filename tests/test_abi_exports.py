@@ -23,3 +23,23 @@ def test_ops_refuse_cpu_tensors():
     from diffalign_amd import _lib as L
     with pytest.raises(L.DiffAlignHipError):
         L.ptr(torch.zeros(3))
+
+
+def test_ptr_keeps_temporaries_alive_until_check():
+    """A temporary passed to ptr() inside a call expression must survive until the entry point has been called."""
+    import weakref
+    import torch
+    from diffalign_amd import _lib as L
+    if not torch.cuda.is_available():
+        t = torch.zeros(4)
+        L._held.append(t); r = weakref.ref(t); del t
+        assert r() is not None
+        L.check(0, 'noop')
+        assert r() is None
+        return
+    t = torch.zeros(4, device='cuda')
+    r = weakref.ref(t)
+    L.ptr(t); del t
+    assert r() is not None
+    L.check(0, 'noop')
+    assert r() is None

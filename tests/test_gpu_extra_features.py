@@ -99,3 +99,55 @@ def test_model_forward_and_sampling_with_extra_features():
                        atom_map_numbers=true['atom_map_numbers'].to(D), mol_assignments=true['mol_assignments'].to(D))
     out = model.sample_one_batch(data=data)
     assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
+
+
+def _solve(Lap, nm, pn):
+    import ctypes as C
+    from diffalign_amd import _lib as L
+    B, n, _ = Lap.shape
+    Ld = Lap.to(D).contiguous().clone()
+    nm8, pnd = nm.to(D).view(torch.uint8).contiguous(), pn.to(D).contiguous()     # (kept alive until the launch has been enqueued)
+    ev6 = torch.zeros(B, 6, dtype=torch.float64, device=D)
+    nc = torch.empty(B, device=D); ev5 = torch.empty(B, 5, device=D); nl = torch.empty(B, n, device=D); v2 = torch.empty(B, n, 2, device=D)
+    L.check(L.lib().da_extra_eigen_solve(L.ptr(Ld), L.ptr(nm8), L.ptr(pnd), L.ptr(nc), L.ptr(ev5),
+                                         L.ptr(nl), L.ptr(v2), L.ptr(ev6), C.c_int(B), C.c_int(n), L.stream()), 'da_extra_eigen_solve')
+    torch.cuda.synchronize()
+    return nc.cpu(), ev5.cpu(), nl.cpu(), v2.cpu(), ev6.cpu()
+
+
+@pytest.mark.parametrize('n,p,B', [(1, 0.0, 2), (2, 1.0, 2), (3, 0.5, 3), (37, 0.08, 4), (64, 0.6, 3), (300, 0.01, 3), (300, 0.2, 2), (513, 0.004, 1)])
+def test_partial_eigensolver_vs_lapack(n, p, B):
+    """da_extra_eigen_solve (one launch: Householder tridiagonalisation, Sturm multisection, inverse iteration) against
+    torch.linalg.eigh on the CPU (LAPACK, fp64): the count below the threshold, eigenvalue 0 and the 5 after the zero ones to
+    1e-9 * ||L||, and the two returned eigenvectors as eigenvectors (residual 1e-8 * ||L||, unit norm)."""
+    g = torch.Generator().manual_seed(1000 + n)
+    nm = torch.ones(B, n, dtype=torch.bool)
+    if n > 8:
+        nm[0, n - n // 5:] = False                                  # one graph with padding
+    A = (torch.rand(B, n, n, generator=g) < p).double(); A = torch.triu(A, 1); A = A + A.transpose(1, 2)
+    A = A * nm[:, :, None] * nm[:, None, :]
+    Lap = torch.diag_embed(A.sum(-1)) - A
+    Lap = Lap + torch.diag_embed((~nm).double() * 2 * n)
+    pn = torch.randn(B, n, generator=g)
+    nc, ev5, nl, v2, ev6 = _solve(Lap, nm, pn)
+    w, _ = torch.linalg.eigh(Lap)
+    nreal = nm.sum(1).double()
+    scale = max(1.0, float(Lap.abs().sum(-1).max()))
+    for b in range(B):
+        ncomp = int((w[b] / nreal[b] < 1e-5).sum())
+        assert int(nc[b]) == ncomp
+        assert abs(float(ev6[b, 0] - w[b, 0])) <= 1e-9 * scale
+        for k in range(5):
+            if ncomp + k < n:
+                assert abs(float(ev6[b, 1 + k] - w[b, ncomp + k])) <= 1e-9 * scale, (b, k)
+                assert abs(float(ev5[b, k]) - float(w[b, ncomp + k] / nreal[b])) <= 1e-6 * max(1.0, float(w[b, ncomp + k] / nreal[b]))
+            else:
+                assert float(ev5[b, k]) == 2.0
+        for k in range(2):
+            col = ncomp + k
+            if col < n and bool(nm[b, col]):
+                vfull = v2[b, :, k].double()
+                if bool(nm[b].all()):                                   # (masked rows are zeroed in the feature, not in the vector)
+                    assert abs(float(vfull.norm()) - 1) <= 1e-5
+                    assert float((Lap[b] @ vfull - w[b, col] * vfull).abs().max()) <= 1e-5 * scale, (b, k)
+        assert (nl[b][~nm[b]] == 0).all()

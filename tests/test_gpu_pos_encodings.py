@@ -43,7 +43,8 @@ def test_laplacian_encodings_properties():
     Lk = torch.empty(4, 64, 64, device=D)
     from diffalign_amd import _lib as L
     import ctypes as C
-    L.check(L.lib().da_pos_laplacian(L.ptr(E.to(D).contiguous()), L.ptr(mol.to(D).contiguous()), L.ptr(Lk), C.c_int(4), C.c_int(64), L.stream()), 'lap')
+    Ed, mold = E.to(D).contiguous(), mol.to(D).contiguous()
+    L.check(L.lib().da_pos_laplacian(L.ptr(Ed), L.ptr(mold), L.ptr(Lk), C.c_int(4), C.c_int(64), L.stream()), 'lap')
     torch.testing.assert_close(Lk.cpu(), laps, atol=1e-6, rtol=0)
     for b in range(4):
         isprod = mol[b] == mol[b].max()

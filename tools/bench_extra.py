@@ -26,4 +26,4 @@ for t in (50, 250, 450):
     A, Lap, vw, vp = XF._adjacency(E, nm8, bo, True)
     print(f't={t}: total {timed(lambda: XF.compute_extra_features(X, E, nm, ef, mf, pad_noise=pn)):.2f} ms | adjacency {timed(lambda: XF._adjacency(E, nm8, bo, True)):.3f}'
           f' | cycles (2 bmm + kernel) {timed(lambda: XF._cycles(A, nm8)):.3f} | eigh fp64 {timed(lambda: torch.linalg.eigh(Lap)):.2f}'
-          f' | eigh fp32 {timed(lambda: torch.linalg.eigh(Lap.float())):.2f} | eigen kernel+eigh {timed(lambda: XF._eigen(Lap, nm8, pn)):.2f} ms', flush=True)
+          f' | eigen via torch.linalg.eigh {timed(lambda: XF._eigen(Lap.clone(), nm8, pn, solver="torch")):.2f} | eigen via da_extra_eigen_solve {timed(lambda: XF._eigen(Lap.clone(), nm8, pn, solver="hip")):.2f} ms', flush=True)

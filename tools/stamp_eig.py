@@ -1,0 +1,26 @@
+"""Phase cycle counts of da_extra_eigen_solve (EXP_EIG_STAMP build).  DA_LIB=... python tools/stamp_eig.py"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from types import SimpleNamespace
+import torch
+from diffalign_amd import extra_features as XF, synthetic as S, _lib as L
+from tests.golden.common import extra_info, ATOMS
+B, n = 64, 300
+D = torch.device('cuda:0')
+info = extra_info(SimpleNamespace)
+true = S.make_reaction_batch(B, n, seed=5, P=142)
+mf = XF.ExtraMolecularFeatures(info)
+z = S.noised_state(true, 250, 500, len(ATOMS) - 2, seed=6)
+E, nm = z['E'].to(D), z['node_mask'].to(D)
+nm8 = nm.view(torch.uint8)
+A, Lap, vw, vp = XF._adjacency(E, nm8, mf.consts(D)[1], True)
+pn = torch.randn(B, n, device=D)
+out = torch.zeros(B, 6, dtype=torch.float64, device=D)
+nc = torch.empty(B, device=D); ev5 = torch.empty(B, 5, device=D); nl = torch.empty(B, n, device=D); v2 = torch.empty(B, n, 2, device=D)
+for _ in range(2):
+    Lc = Lap.clone()
+    L.check(L.lib().da_extra_eigen_solve(L.ptr(Lc), L.ptr(nm8), L.ptr(pn), L.ptr(nc), L.ptr(ev5), L.ptr(nl), L.ptr(v2), L.ptr(out), C.c_int(B), C.c_int(n), L.stream()), 'x')
+torch.cuda.synchronize()
+o = out.cpu()
+print('mean k-cycles per graph: tridiag %.0f  eigenvalues %.0f  inverse iteration %.0f  back-transform %.0f' % tuple((o[:, :4].mean(0) / 1e3).tolist()))
+print('max  k-cycles per graph: tridiag %.0f  eigenvalues %.0f  inverse iteration %.0f  back-transform %.0f' % tuple((o[:, :4].max(0).values / 1e3).tolist()))
