@@ -5,8 +5,8 @@
 // every step after moving E, X and node_mask to the host (diffusion/diffusion_abstract.py:350-372).
 //
 // Division of work: this file holds the passes over the (B,n,n,ke) edge state and the small per-graph reductions; the
-// two adjacency powers A^2, A^3 are plain library GEMMs (torch.bmm) and the batched symmetric eigendecomposition is
-// torch.linalg.eigh on the device (fp64, as the reference) -- both called from diffalign_amd/extra_features.py.
+// two adjacency powers A^2, A^3 are plain library GEMMs (torch.bmm) and the eigen-decomposition is k_extra_eig.hip (or,
+// optionally, torch.linalg.eigh on the device followed by k_extra_eigen below) -- see diffalign_amd/extra_features.py.
 // All kernels here are HBM/latency bound: E is read once (28 B per ordered pair), the three n x n fp32 matrices once.
 //
 // The cycle formulas use A = A^T (the diffusion state is symmetric by construction, helpers.py:743-745):

@@ -3,7 +3,7 @@
 // The reference takes a full fp64 torch.linalg.eigh of every (n,n) Laplacian at every step and then uses only: the number
 // of eigenvalues below 1e-5 * n_real, the 5 eigenvalues after those, eigenvector 0 and the 2 eigenvectors after the
 // (near-)zero ones (neuralnet/extra_features.py:117-128, :158-204).  The library routine (rocSOLVER syevd, batched) needs
-// 11.7 ms for 64 matrices of order 300: it is a chain of some thousand small launches.  Here, per graph and in ONE launch:
+// 11.7 ms for 64 matrices of order 300.  Here, per graph and in ONE launch:
 //   1. Householder tridiagonalisation in place (fp64, reflectors kept in the rows they annihilate), skipping rows that
 //      are already zero (isolated nodes, padding: most of a noised reaction graph);
 //   2. Sturm counts / bisection on the tridiagonal matrix for exactly the eigenvalues that are used;
@@ -31,6 +31,23 @@ __device__ __forceinline__ double bsum(double v, double* s_red) {
 #pragma unroll
   for (int w = 0; w < EIG_THREADS / 64; ++w) t += s_red[w];
   return t;
+}
+
+// ordered compaction of {j < k : pred(j)} into list[] (LDS); returns the count to every thread.  One index per thread
+// (k <= EIG_THREADS); cnt: 16 ints of LDS.  Two barriers.
+template <class Pred>
+__device__ __forceinline__ int compact(int* list, int* cnt, int k, Pred pred) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool f = tid < k && pred(tid);
+  const unsigned long long m = __ballot(f);
+  if (lane == 0) cnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < EIG_THREADS / 64; ++w) { const int c = cnt[w]; off += w < wave ? c : 0; tot += c; }
+  if (f) list[off + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+  __syncthreads();
+  return tot;
 }
 
 // number of eigenvalues of the tridiagonal (d, e) [e[i] couples i-1 and i, e[0] unused] that are < x
@@ -117,6 +134,8 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   // allows: reductions through per-wave partials that every thread sums itself, p accumulated with LDS atomics, q never
   // materialised.
   double* s_part = s_red;          // [2][16] per-wave partials, double buffered
+  int* s_iu = reinterpret_cast<int*>(s_w);             // [n] compacted index list
+  int* s_wc = reinterpret_cast<int*>(s_w + n);         // [16] per-wave counts of the compaction
   for (int k = n - 1; k >= 1; --k) {
     double part = 0.0;
     for (int j = tid; j < k; j += EIG_THREADS) { const double x = A[(size_t)k * n + j]; s_u[j] = x; s_p[j] = 0.0; if (j < k - 1) part += x * x; }
@@ -138,53 +157,62 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
     __syncthreads();                                                              // (2) everyone has read f
     if (tid == 0) { s_e[k] = g; s_h[k] = h; s_u[k - 1] = f - g; }
     __syncthreads();                                                              // (3)
-    // h p = A u.  A is symmetric: (A u)_j = sum_i A[i][j] u_i, one thread per column j and row class (i mod RC), the rows
-    // walked with 16 independent loads in flight; coalesced in j; partial sums meet in LDS atomics
+    // The reflector lives inside the connected component of node k (a reaction graph is many components: the product, the
+    // reactant fragments, isolated atoms), everything outside is exactly zero and is skipped: U = {j: u_j != 0} bounds the
+    // rows of the product A u, T = {j: u_j != 0 or (A u)_j != 0} the rank-2 update.  Ordered compaction (deterministic sums).
+    const int nU = compact(s_iu, s_wc, k, [&](int j) { return s_u[j] != 0.0; });
+    // h p = A u.  A is symmetric: (A u)_j = sum_{i in U} A[i][j] u_i, one thread per column j and row class, the rows walked
+    // with 16 independent loads in flight; coalesced in j; partial sums meet in LDS atomics
     const int CW = (k + 63) & ~63;                      // columns rounded up to whole waves
     const int RC = EIG_THREADS / CW > 0 ? EIG_THREADS / CW : 1;
     for (int t = tid; t < RC * CW; t += EIG_THREADS) {
       const int j = t % CW, rc = t / CW;
       if (j >= k) continue;
       double acc[4] = {0, 0, 0, 0};
-      int i = rc;
-      for (; i + 15 * RC < k; i += 16 * RC) {
-        double v[16];
+      int ii = rc;
+      for (; ii + 15 * RC < nU; ii += 16 * RC) {
+        double v[16]; int ix[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = A[(size_t)(i + q * RC) * n + j];
+        for (int q = 0; q < 16; ++q) { ix[q] = s_iu[ii + q * RC]; v[q] = A[(size_t)ix[q] * n + j]; }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q & 3] = fma(v[q], s_u[i + q * RC], acc[q & 3]);
+        for (int q = 0; q < 16; ++q) acc[q & 3] = fma(v[q], s_u[ix[q]], acc[q & 3]);
       }
-      for (; i < k; i += RC) acc[0] = fma(A[(size_t)i * n + j], s_u[i], acc[0]);
-      atomicAdd(&s_p[j], (acc[0] + acc[1]) + (acc[2] + acc[3]));
+      for (; ii < nU; ii += RC) { const int i = s_iu[ii]; acc[0] = fma(A[(size_t)i * n + j], s_u[i], acc[0]); }
+      const double tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      if (tot != 0.0) atomicAdd(&s_p[j], tot);
     }
     __syncthreads();                                                              // (4)
     double kp = 0.0;
     for (int j = tid; j < k; j += EIG_THREADS) kp = fma(s_u[j], s_p[j], kp);
     kp = wsum(kp);
     if (lane == 0) s_part[16 + wave] = kp;
-    __syncthreads();                                                              // (5)
+    const int nT = compact(s_iu, s_wc, k, [&](int j) { return s_u[j] != 0.0 || s_p[j] != 0.0; });   // (barriers inside)
     double upu = 0.0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) upu += s_part[16 + w];
     const double invh = 1.0 / h;
     const double K = upu * invh * invh * 0.5;           // u^T p / (2h) with p = (A u) / h
-    // A -= u q^T + q u^T on the leading k x k block, q = p - K u formed on the fly; row k keeps the reflector
-    for (int t = tid; t < RC * CW; t += EIG_THREADS) {
-      const int j = t % CW, rc = t / CW;
-      if (j >= k) continue;
+    // A -= u q^T + q u^T on T x T, q = p - K u formed on the fly; row k keeps the reflector
+    const int CT = (nT + 63) & ~63;
+    const int RT = EIG_THREADS / CT > 0 ? EIG_THREADS / CT : 1;
+    for (int t = tid; t < RT * CT; t += EIG_THREADS) {
+      const int jj = t % CT, rc = t / CT;
+      if (jj >= nT) continue;
+      const int j = s_iu[jj];
       const double uj = s_u[j], qj = s_p[j] * invh - K * uj;
-      int i = rc;
-      for (; i + 15 * RC < k; i += 16 * RC) {
-        double v[16];
+      int ii = rc;
+      for (; ii + 15 * RT < nT; ii += 16 * RT) {
+        double v[16]; int ix[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = A[(size_t)(i + q * RC) * n + j];
+        for (int q = 0; q < 16; ++q) { ix[q] = s_iu[ii + q * RT]; v[q] = A[(size_t)ix[q] * n + j]; }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const double ui = s_u[i + q * RC], qi = s_p[i + q * RC] * invh - K * ui;
-          A[(size_t)(i + q * RC) * n + j] = v[q] - (ui * qj + qi * uj);
+          const double ui = s_u[ix[q]], qi = s_p[ix[q]] * invh - K * ui;
+          A[(size_t)ix[q] * n + j] = v[q] - (ui * qj + qi * uj);
         }
       }
-      for (; i < k; i += RC) {
+      for (; ii < nT; ii += RT) {
+        const int i = s_iu[ii];
         const double ui = s_u[i], qi = s_p[i] * invh - K * ui;
         A[(size_t)i * n + j] -= ui * qj + qi * uj;
       }
@@ -227,7 +255,7 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
     double* s_br = s_w + 8;                             // [6][2] brackets
     if (tid < 6) { s_br[2 * tid] = gl; s_br[2 * tid + 1] = gu; }
     __syncthreads();
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < 8; ++round) {          // 161^8 = 4.5e17: the bracket shrinks to rounding level
       if (tid < 6) s_lo[tid] = -1;
       __syncthreads();
       if (ev < 6) {

@@ -4,7 +4,8 @@ Host-side mirror of the reference's `ExtraFeatures` (neuralnet/extra_features.py
 (neuralnet/extra_features_molecular.py:6-26): same constructor arguments, same `forward` signatures and return
 tuples.  The reference moves E, X and node_mask to the CPU at every step (diffusion_abstract.py:361-364); here everything
 stays on the device: HIP kernels (csrc/k_extra.hip) for the passes over the edge state and the per-graph reductions,
-`torch.bmm` for the two adjacency powers and `torch.linalg.eigh` (fp64, like the reference) for the Laplacian.
+`torch.bmm` for the two adjacency powers and, for the Laplacian, a one-launch batched partial eigensolver in fp64
+(csrc/k_extra_eig.hip; `DA_EXTRA_EIGH=torch` selects `torch.linalg.eigh`, the reference's routine, instead).
 
 Requires a symmetric E (every diffusion state is: helpers.py:743-745) -- the cycle formulas use A = A^T.
 The eigenvector features (not-in-largest-component flag, two lowest non-trivial eigenvectors) depend on the basis the
@@ -47,7 +48,7 @@ def _cycles(A: torch.Tensor, nm_u8: torch.Tensor):
 
 
 # 'hip' (default): the one-launch batched partial eigensolver of csrc/k_extra_eig.hip; 'torch': torch.linalg.eigh (rocSOLVER
-# syevd, fp64, the reference's routine) followed by k_extra_eigen -- 4x slower at B = 64, n = 300, kept for cross-checks.
+# syevd, fp64, the reference's routine) followed by k_extra_eigen -- 3.5x slower at B = 64, n = 300, kept for cross-checks.
 EIGENSOLVER = os.environ.get('DA_EXTRA_EIGH', 'hip')
 
 
