@@ -151,3 +151,36 @@ def test_partial_eigensolver_vs_lapack(n, p, B):
                     assert abs(float(vfull.norm()) - 1) <= 1e-5
                     assert float((Lap[b] @ vfull - w[b, col] * vfull).abs().max()) <= 1e-5 * scale, (b, k)
         assert (nl[b][~nm[b]] == 0).all()
+
+
+@pytest.mark.parametrize('n,reals', [(1, [1, 1]), (2, [2, 1]), (5, [5, 3, 0 + 1])])
+def test_extra_features_tiny_graphs_vs_oracle(n, reals):
+    """Degenerate sizes: one or two nodes, graphs that are almost all padding, B = 0."""
+    from diffalign_amd import extra_features as XF
+    info = extra_info(SimpleNamespace)
+    B = len(reals)
+    g = torch.Generator().manual_seed(50 + n)
+    kx, ke = len(ATOMS), 7
+    nm = torch.zeros(B, n, dtype=torch.bool)
+    X = torch.zeros(B, n, kx); E = torch.zeros(B, n, n, ke)
+    for b, r in enumerate(reals):
+        nm[b, :r] = True
+        X[b, torch.arange(r), torch.randint(1, kx - 1, (r,), generator=g)] = 1
+        cls = torch.randint(0, 4, (r, r), generator=g); cls = torch.triu(cls, 1); cls = cls + cls.t()
+        E[b, :r, :r] = torch.nn.functional.one_hot(cls, ke).float()
+        E[b, torch.arange(n), torch.arange(n)] = 0
+    pn = torch.randn(B, n, generator=g)
+    Xo, yo = O.extra_features(X, E, nm, info.max_n_nodes, info.valencies, info.bond_orders, info.atom_weights.values(), info.max_weight, pn)
+    ef, mf = XF.ExtraFeatures('all', info), XF.ExtraMolecularFeatures(info)
+    for solver in ('hip', 'torch'):
+        XF.EIGENSOLVER = solver
+        try:
+            Xe, ye = XF.compute_extra_features(X.to(D), E.to(D), nm.to(D), ef, mf, pad_noise=pn.to(D))
+        finally:
+            XF.EIGENSOLVER = 'hip'
+        torch.testing.assert_close(Xe.cpu()[..., :3], Xo[..., :3], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(Xe.cpu()[..., 6:], Xo[..., 6:], atol=0, rtol=0)
+        torch.testing.assert_close(ye.cpu(), yo, atol=2e-5, rtol=1e-5)
+        assert (Xe.cpu()[..., 3:6][~nm] == 0).all()
+    Xe, ye = XF.compute_extra_features(X[:0].to(D), E[:0].to(D), nm[:0].to(D), ef, mf)
+    assert Xe.shape == (0, n, 8) and ye.shape == (0, 12)
