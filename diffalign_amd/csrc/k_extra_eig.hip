@@ -50,16 +50,28 @@ __device__ __forceinline__ int compact(int* list, int* cnt, int k, Pred pred) {
   return tot;
 }
 
-// number of eigenvalues of the tridiagonal (d, e) [e[i] couples i-1 and i, e[0] unused] that are < x
+// number of eigenvalues of the tridiagonal (d, e) [e[i] couples i-1 and i, e[0] unused] that are < x: sign changes of the
+// leading principal minors p_i = (d_i - x) p_{i-1} - e_i^2 p_{i-2}, kept in range by rescaling (two dependent FMAs per row
+// instead of the fp64 division of the ratio form; a vanishing minor counts as a change and is nudged, as LAPACK's pivmin)
 __device__ int sturm_count(const double* d, const double* e, int n, double x, double pivmin) {
-  int cnt = 0;
-  double q = d[0] - x;
-  if (fabs(q) < pivmin) q = -pivmin;
-  cnt += q < 0.0;
-  for (int i = 1; i < n; ++i) {
-    q = d[i] - x - e[i] * e[i] / q;
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < 0.0;
+  double pm = 1.0, p = d[0] - x;
+  if (fabs(p) < pivmin) p = -pivmin;
+  int cnt = p < 0.0;
+  for (int i0 = 1; i0 < n; i0 += 8) {                 // eight rows' LDS reads in flight together, branch-free arithmetic
+    double dd[8], ee[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int i = min(i0 + q, n - 1); dd[q] = d[i]; ee[q] = e[i]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (i0 + q < n) {                                // uniform
+        double pn = fma(dd[q] - x, p, -(ee[q] * ee[q]) * pm);
+        pn = fabs(pn) < pivmin * fabs(p) ? -pivmin * p : pn;          // |p_i / p_{i-1}| < pivmin
+        cnt += (pn < 0.0) != (p < 0.0);
+        const double ap = fabs(pn);
+        const double sc = ap > 1e100 ? 1e-100 : (ap < 1e-100 ? 1e100 : 1.0);
+        pm = p * sc; p = pn * sc;
+      }
+    }
   }
   return cnt;
 }
@@ -76,34 +88,33 @@ __device__ double bisect(const double* d, const double* e, int n, int k, double 
 }
 
 // one inverse-iteration solve (T - lam I) y = y in place: Gaussian elimination with partial pivoting on the tridiagonal
-// (work arrays a, b, c, f of length n in LDS / global), sequential, one thread
+// (U keeps two super-diagonals b, c; work arrays a, b, c of length n in LDS), sequential, one thread.  The row being
+// eliminated is carried in registers, so the only loop-carried chain is the arithmetic, not LDS round trips.
 __device__ void tri_solve(const double* d, const double* e, int n, double lam, double* y, double* a, double* b, double* c, double eps) {
-  // rows: sub-diagonal e[i] (i>=1), diagonal d[i]-lam, super-diagonal e[i+1]; U has two super-diagonals (b, c)
-  for (int i = 0; i < n; ++i) { a[i] = d[i] - lam; b[i] = (i + 1 < n) ? e[i + 1] : 0.0; c[i] = 0.0; }
+  double ai = d[0] - lam, bi = n > 1 ? e[1] : 0.0, yi = y[0];          // current row i: diagonal, first super-diagonal, rhs
+#pragma unroll 4
   for (int i = 0; i + 1 < n; ++i) {
-    const double sub = e[i + 1];
-    if (fabs(sub) > fabs(a[i])) {                 // swap rows i and i+1
-      double t = a[i]; a[i] = sub; const double ai1 = a[i + 1];
-      const double bi = b[i]; b[i] = ai1; c[i] = b[i + 1];
-      t = t; const double yi = y[i]; y[i] = y[i + 1];
-      // eliminate: new row i+1 = old row i - m * new row i
-      const double piv = a[i] == 0.0 ? eps : a[i];
-      const double m = t / piv;
-      a[i + 1] = bi - m * b[i];
-      b[i + 1] = -m * c[i];
-      y[i + 1] = yi - m * y[i];
+    const double sub = e[i + 1];                                       // row i+1: sub, diagonal, super
+    const double dn = d[i + 1] - lam, sn = (i + 2 < n) ? e[i + 2] : 0.0, yn = y[i + 1];
+    if (fabs(sub) > fabs(ai)) {                                        // swap rows i and i+1
+      const double m = ai / sub;
+      a[i] = sub; b[i] = dn; c[i] = sn; y[i] = yn;
+      ai = bi - m * dn; bi = -m * sn; yi = yi - m * yn;
     } else {
-      const double piv = a[i] == 0.0 ? eps : a[i];
-      a[i] = piv;
+      const double piv = ai == 0.0 ? eps : ai;
       const double m = sub / piv;
-      a[i + 1] -= m * b[i];
-      y[i + 1] -= m * y[i];
+      a[i] = piv; b[i] = bi; c[i] = 0.0; y[i] = yi;
+      ai = dn - m * bi; bi = sn; yi = yn - m * yi;
     }
   }
-  if (a[n - 1] == 0.0) a[n - 1] = eps;
-  y[n - 1] /= a[n - 1];
-  if (n >= 2) { const double piv = a[n - 2] == 0.0 ? eps : a[n - 2]; y[n - 2] = (y[n - 2] - b[n - 2] * y[n - 1]) / piv; }
-  for (int i = n - 3; i >= 0; --i) { const double piv = a[i] == 0.0 ? eps : a[i]; y[i] = (y[i] - b[i] * y[i + 1] - c[i] * y[i + 2]) / piv; }
+  if (ai == 0.0) ai = eps;
+  double y1 = yi / ai, y2 = 0.0;                                       // y[i+1], y[i+2] of the back substitution
+  y[n - 1] = y1;
+#pragma unroll 4
+  for (int i = n - 2; i >= 0; --i) {
+    const double v = (y[i] - b[i] * y1 - c[i] * y2) / a[i];
+    y[i] = v; y2 = y1; y1 = v;
+  }
 }
 
 __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restrict__ Lmat, const uint8_t* __restrict__ node_mask,
@@ -246,16 +257,16 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   if (tid == 0) s_ncomp = sturm_count(s_d, s_e, n, 1e-5 * nreal, pivmin);          // eigenvalue / n_real < 1e-5  (:119, :166)
   __syncthreads();
   const int ncomp = s_ncomp;
-  // six eigenvalues (indices 0, ncomp .. ncomp+4) by multisection: 160 threads per eigenvalue evaluate the Sturm count at
-  // 160 interior points of the current bracket at once (7.3 bits per round instead of 1)
+  // six eigenvalues (indices 0, ncomp .. ncomp+4) by multisection: 42 threads per eigenvalue evaluate the Sturm count at
+  // 42 interior points of the current bracket at once (5.4 bits per round instead of 1)
   {
-    constexpr int PTS = 160;
+    constexpr int PTS = 42;                             // 6 x 42 threads = 4 waves, one per SIMD: the count is fp64-VALU bound
     const int ev = tid / PTS, pt = tid - ev * PTS;
     int* s_lo = reinterpret_cast<int*>(s_w);            // [6] index of the last point with count <= idx, per round
     double* s_br = s_w + 8;                             // [6][2] brackets
     if (tid < 6) { s_br[2 * tid] = gl; s_br[2 * tid + 1] = gu; }
     __syncthreads();
-    for (int round = 0; round < 8; ++round) {          // 161^8 = 4.5e17: the bracket shrinks to rounding level
+    for (int round = 0; round < 11; ++round) {         // 43^11 = 9e17: the bracket shrinks to rounding level
       if (tid < 6) s_lo[tid] = -1;
       __syncthreads();
       if (ev < 6) {
