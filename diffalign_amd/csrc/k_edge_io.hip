@@ -57,7 +57,8 @@ __device__ __forceinline__ void mlp_in_chain(const float* __restrict__ src, int 
 
 template <int DE, int HE>
 __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in, int de_in, const uint8_t* __restrict__ nm,
-                                                 const uint4* __restrict__ blob, bf16_t* __restrict__ E_out, int B, int n) {
+                                                 const uint4* __restrict__ blob, bf16_t* __restrict__ E_out, int B, int n,
+                                                 const uint8_t* __restrict__ sym_flags) {
   using C = EdgeIoCfg<DE, HE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sW = reinterpret_cast<uint4*>(smem);
@@ -76,11 +77,16 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
       const float* pij = E_in + ((size_t)row * n + jc) * de_in;
       const float* pji = E_in + (((size_t)b * n + jc) * n + i) * de_in;
       // symmetric input tile (the diffusion state always is): mlp(E_ij) == mlp(E_ji) bit for bit, one evaluation is enough
-      bool same = true;
+      bool sym_tile;                                   // wave-uniform
+      if (sym_flags) {
+        sym_tile = sym_flags[b] != 0;                  // whole graph checked beforehand with coalesced tile reads (k_edge_sym_flags)
+      } else {
+        bool same = true;
 #ifndef EXP_IN_NOMIRROR
-      for (int c = 8 * h; c < min(de_in, 8 * h + 8); ++c) same = same && (pij[c] == pji[c]);
+        for (int c = 8 * h; c < min(de_in, 8 * h + 8); ++c) same = same && (pij[c] == pji[c]);
 #endif
-      const bool sym_tile = __all(same);               // wave-uniform
+        sym_tile = __all(same);
+      }
       mlp_in_chain<DE, HE>(pij, de_in, h, lane, sW0, sW1, sP, o);
       const float pm = (mi && jvalid && nm[b * n + jc] && jc != i) ? 1.f : 0.f;
       float sum = 0.f;
@@ -113,6 +119,30 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
       }
     }
   }
+}
+
+// flags[b] = 0 unless E_in[b] is bitwise symmetric in (i,j) over all de_in channels.  One workgroup per pair of mirrored
+// 32x32 tiles, both read row-wise (coalesced) and met in LDS; flags must be 1 on entry.
+__global__ void __launch_bounds__(256) k_edge_sym_flags(const float* __restrict__ E_in, int de_in, int n, uint8_t* __restrict__ flags) {
+  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
+  if (jt < it) return;
+  extern __shared__ float st[];                       // [32][32 * de_in] tile (it, jt), rows i, row-major
+  const int W = 32 * de_in;
+  const float* base = E_in + (size_t)b * n * n * de_in;
+  for (int t = threadIdx.x; t < 32 * W; t += 256) {
+    const int ri = t / W, o = t - ri * W;
+    const int i = it * 32 + ri, j = jt * 32 + o / de_in;
+    st[t] = (i < n && j < n) ? base[((size_t)i * n + jt * 32) * de_in + o] : 0.f;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int t = threadIdx.x; t < 32 * W; t += 256) {   // tile (jt, it): rows j, columns i
+    const int rj = t / W, o = t - rj * W;
+    const int ci = o / de_in, c = o - ci * de_in;
+    const int j = jt * 32 + rj, i = it * 32 + ci;
+    if (i < n && j < n) bad = bad || (base[((size_t)j * n + it * 32) * de_in + o] != st[ci * W + rj * de_in + c]);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) flags[b] = 0;
 }
 
 // ---- output stage: logits E_o = sym((mlp_out_E(E_h) + E_in[..., :Ke]) * offdiag) (+ product->reactant skip) ------
@@ -253,9 +283,15 @@ __global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict
 static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
 
 template <int DE, int HE>
-static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s) {
+static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s,
+                     uint8_t* sym_flags = nullptr) {
   using C = EdgeIoCfg<DE, HE>;
-  k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n);
+  if (sym_flags) {
+    if (hipMemsetAsync(sym_flags, 1, B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
+    const int nt = (n + 31) / 32;
+    k_edge_sym_flags<<<dim3(nt, nt, B), 256, 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, n, sym_flags);
+  }
+  k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n, sym_flags);
   return DA_OK;
 }
 template <int DE, int HE>
@@ -288,6 +324,22 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
   else if (de == 32 && he == 32) launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream);
   else { da_set_error("da_edge_in: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_in");
+  return DA_OK;
+}
+
+// da_edge_in with the symmetry of every input graph established beforehand by a coalesced pass (sym_flags: B bytes of
+// scratch the caller owns) instead of a transposed, uncoalesced read per pair.  Same result, bit for bit.
+int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
+                   int n, int de, int he, void* stream) {
+  DA_CHECK_ARG(de_in >= 1 && de_in <= 16, "da_edge_in_sym: input edge feature width %d not in 1..16", de_in);
+  DA_CHECK_ARG(sym_flags != nullptr, "da_edge_in_sym: sym_flags scratch (B bytes) is null");
+  if (B == 0 || n == 0) return DA_OK;
+  int rc;
+  if (de == 64 && he == 128) rc = launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, sym_flags);
+  else if (de == 32 && he == 32) rc = launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, sym_flags);
+  else { da_set_error("da_edge_in_sym: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  if (rc) return rc;
+  DA_CHECK_LAUNCH("da_edge_in_sym");
   return DA_OK;
 }
 

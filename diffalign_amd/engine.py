@@ -220,8 +220,9 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     pos = pos_encodings.contiguous().float() if pos_encodings is not None else None
     L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), S), 'da_x_in_finish')
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
-    L.check(lib.da_edge_in(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), _i(B), _i(n), _i(pm.de), _i(pm.he), S),
-            'da_edge_in')
+    sym_flags = torch.empty(B, dtype=torch.uint8, device=dev)
+    L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
+                               _i(pm.he), S), 'da_edge_in_sym')
     yh = torch.empty(B, pm.dy, device=dev)
     L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')

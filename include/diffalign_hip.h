@@ -132,6 +132,10 @@ int da_x_in_finish(float* X_h, const uint8_t* node_mask, const float* pos_encodi
 /* E_h(bf16) = encode_no_element(mask(sym(mlp_in_E(E))))  (transformer_model_with_y.py:657-661; 1 <= de_in <= 16). */
 int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
                int he, void* stream);
+/* da_edge_in with a per-graph symmetry pre-pass (coalesced 32x32 tile reads) instead of one transposed read per pair:
+ * sym_flags = B bytes of caller-owned scratch.  Bit-identical to da_edge_in. */
+int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
+                   int n, int de, int he, void* stream);
 
 /* y_h = mlp_in_y(y)  (transformer_model_with_y.py:590-591), fp32. */
 int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, float* out, int B, int din,

@@ -86,6 +86,18 @@ def test_stages_vs_oracle(dims):
     _, ref = O.mask_dense(torch.zeros(B, n, 1), ref, nm)
     assert rel_l2(Eh2.float(), ref) <= 1e-2
     assert torch.equal(Eh2, Eh2.transpose(1, 2))
+    # -- da_edge_in_sym (symmetry established per graph by a coalesced pre-pass): bit-identical, on symmetric, non-symmetric and
+    #    mixed batches (graph 1 made non-symmetric in a single entry)
+    Emix = E.clone(); Emix[1, 3, 5, 2] += 0.25
+    flags = torch.empty(B, dtype=torch.uint8, device=D)
+    for src_ in (E_d, Ea_d, Emix.to(D)):
+        a_ = torch.empty_like(Eh); b_ = torch.empty_like(Eh)
+        L.check(L.lib().da_edge_in(L.ptr(src_), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(a_), engine._i(B),
+                                   engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in')
+        L.check(L.lib().da_edge_in_sym(L.ptr(src_), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(b_), L.ptr(flags), engine._i(B),
+                                       engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in_sym')
+        assert torch.equal(a_, b_)
+    assert flags.cpu().tolist() == [1, 0, 1]
     # -- one layer on random hidden features
     g = torch.Generator().manual_seed(3)
     Xh = torch.randn(B, n, hd['dx'], generator=g); yh = torch.randn(B, hd['dy'], generator=g)
