@@ -246,6 +246,104 @@ __global__ void k_posterior_E(const float* logits, const float* zt, const uint8_
   }
 }
 
+// posterior_elem with the per-(xt, k0, k) factor (Qt[k][xt] * Qsb[k0][k]) / d[k0] taken from a table M[xt][k0][k] that was
+// filled with exactly that expression: same operations on the same values in the same order => same bits.
+template <int K>
+__device__ __forceinline__ void posterior_elem_tab(const float* __restrict__ logit, int xt, const float* M, float temp, float* u) {
+  float l[K];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { l[k] = logit[k]; mx = fmaxf(mx, l[k]); }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) s += expf(l[k] - mx);
+  float lse = mx + logf(s);
+  float mx2 = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { l[k] = (l[k] - lse) * temp; mx2 = fmaxf(mx2, l[k]); }
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { l[k] = expf(l[k] - mx2); s2 += l[k]; }
+#pragma unroll
+  for (int k = 0; k < K; ++k) u[k] = 0.f;
+  const float* Mx = M + xt * K * K;
+#pragma unroll
+  for (int k0 = 0; k0 < K; ++k0) {
+    float ph = l[k0] / s2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) u[k] += ph * Mx[k0 * K + k];
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) tot += u[k];
+  if (tot == 0.f) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) u[k] = 1e-5f;
+    tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot += u[k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) u[k] = u[k] / tot;
+}
+
+// edges, draw only (no probabilities out): one workgroup per pair of mirrored 32x32 tiles (it <= jt).  Each unordered pair is
+// evaluated ONCE, by its upper-triangle element; the class goes through LDS to both output tiles, which are written
+// row-wise.  Same arithmetic per element as k_posterior_E (bit-identical draws), half the evaluations, no transposed reads.
+template <int K>
+__global__ void __launch_bounds__(256) k_posterior_E_tiles(const float* __restrict__ logits, const float* __restrict__ zt,
+                                                           const uint8_t* __restrict__ nm, const float* __restrict__ Qt,
+                                                           const float* __restrict__ Qsb, const float* __restrict__ Qtb, float temp,
+                                                           const float* __restrict__ noise, const float* __restrict__ orig,
+                                                           const uint8_t* __restrict__ me, float* __restrict__ zs_out, int n) {
+  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
+  if (jt < it) return;
+  __shared__ float sM[K * K * K];
+  __shared__ uint8_t cls[32][33];
+  {
+    const float* qt = Qt + (size_t)b * K * K; const float* qsb = Qsb + (size_t)b * K * K; const float* qtb = Qtb + (size_t)b * K * K;
+    for (int t = threadIdx.x; t < K * K * K; t += 256) {
+      const int xt = t / (K * K), k0 = (t / K) % K, k = t % K;
+      float d = qtb[k0 * K + xt];
+      if (d == 0.f) d = 1e-6f;
+      sM[t] = (qt[k * K + xt] * qsb[k0 * K + k]) / d;
+    }
+  }
+  __syncthreads();
+  const size_t base = (size_t)b * n * n;
+  for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+    const int ri = t >> 5, cj = t & 31, i = it * 32 + ri, j = jt * 32 + cj;
+    int c = 0;
+    if (i < j && j < n && nm[b * n + i] && nm[b * n + j]) {
+      const size_t r = base + (size_t)i * n + j;
+      float u[K];
+      const int xt = onehot_argmax<K>(zt + r * K);
+      posterior_elem_tab<K>(logits + r * K, xt, sM, temp, u);
+      c = race<K>(u, noise + r * K);
+    }
+    cls[ri][cj] = (uint8_t)c;
+  }
+  __syncthreads();
+  constexpr int W = 32 * K;
+  for (int t = threadIdx.x; t < 32 * W; t += 256) {                // tile (it, jt), rows i
+    const int ri = t / W, o = t - ri * W, cj = o / K, k = o - cj * K, i = it * 32 + ri, j = jt * 32 + cj;
+    if (i >= n || j >= n) continue;
+    const int c = i < j ? cls[ri][cj] : (i > j ? cls[cj][ri] : 0); // i > j only inside a diagonal tile
+    const size_t q = (base + (size_t)i * n + j) * K + k;
+    const bool free_ = me ? (me[b * n + i] && me[b * n + j]) : true;
+    zs_out[q] = free_ ? (k == c ? 1.f : 0.f) : orig[q];
+  }
+  if (jt != it)
+    for (int t = threadIdx.x; t < 32 * W; t += 256) {              // tile (jt, it), rows j
+      const int rj = t / W, o = t - rj * W, ci = o / K, k = o - ci * K, j = jt * 32 + rj, i = it * 32 + ci;
+      if (i >= n || j >= n) continue;
+      const int c = cls[ci][rj];
+      const size_t q = (base + (size_t)j * n + i) * K + k;
+      const bool free_ = me ? (me[b * n + i] && me[b * n + j]) : true;
+      zs_out[q] = free_ ? (k == c ? 1.f : 0.f) : orig[q];
+    }
+}
+
 // sample_discrete_features (utils/diffusion/helpers.py:706-752) from explicit probabilities + Exp(1) noise.
 // Bit-exact w.r.t. the reference given identical prob and noise tensors.  Output: class indices (int64).
 __global__ void k_sample_X(const float* prob, const uint8_t* nm, const float* noise, int64_t* out, int rows, int K) {
@@ -329,6 +427,13 @@ template <int K>
 static int launch_post_E(const float* logits, const float* zt, const uint8_t* nm, const float* Qt, const float* Qsb,
                          const float* Qtb, float temp, const float* noise, const float* orig, const uint8_t* me,
                          float* prob, float* zs, int B, int n, hipStream_t s) {
+  if constexpr (K <= 8) {
+    if (!prob && zs) {
+      const int nt = cdiv(n, 32);
+      k_posterior_E_tiles<K><<<dim3(nt, nt, B), 256, 0, s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, me, zs, n);
+      return 0;
+    }
+  }
   dim3 grid(cdiv(n * n, 256), B);
   k_posterior_E<K><<<grid, 256, 0, s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, me, prob, zs, B, n);
   return 0;

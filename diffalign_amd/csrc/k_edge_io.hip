@@ -62,6 +62,11 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
   using C = EdgeIoCfg<DE, HE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sW = reinterpret_cast<uint4*>(smem);
+  if (sym_flags) {                                     // nothing to do when k_edge_in_tiles served every graph
+    int slow = 0;
+    for (int t = threadIdx.x; t < B; t += 256) slow |= !(sym_flags[t] && sym_flags[B + t]);
+    if (!__syncthreads_or(slow)) return;
+  }
   for (int t = threadIdx.x; t < (int)(C::IN_BYTES / 16); t += 256) sW[t] = blob[t];
   __syncthreads();
   const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * 64;
@@ -70,6 +75,7 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
   const int NT = (n + 31) / 32, R = B * n;
   for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
     const int b = row / n, i = row - b * n;
+    if (sym_flags && sym_flags[b] && sym_flags[B + b]) continue;   // symmetric one-hot graph: k_edge_in_tiles wrote it
     const bool mi = nm[row] != 0;
     for (int jt = 0; jt < NT; ++jt) {
       const int jl = jt * 32 + r; const bool jvalid = jl < n; const int jc = jvalid ? jl : n - 1;
@@ -79,7 +85,7 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
       // symmetric input tile (the diffusion state always is): mlp(E_ij) == mlp(E_ji) bit for bit, one evaluation is enough
       bool sym_tile;                                   // wave-uniform
       if (sym_flags) {
-        sym_tile = sym_flags[b] != 0;                  // whole graph checked beforehand with coalesced tile reads (k_edge_sym_flags)
+        sym_tile = sym_flags[b] != 0;                  // whole graph checked beforehand with coalesced tile reads (k_edge_in_tiles)
       } else {
         bool same = true;
 #ifndef EXP_IN_NOMIRROR
@@ -121,28 +127,123 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
   }
 }
 
-// flags[b] = 0 unless E_in[b] is bitwise symmetric in (i,j) over all de_in channels.  One workgroup per pair of mirrored
-// 32x32 tiles, both read row-wise (coalesced) and met in LDS; flags must be 1 on entry.
-__global__ void __launch_bounds__(256) k_edge_sym_flags(const float* __restrict__ E_in, int de_in, int n, uint8_t* __restrict__ flags) {
-  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
+// Symmetric one-hot graphs (every diffusion state is one; masked pairs may be all zero): de_in + 1 distinct results per pair.
+// k_edge_in_table evaluates them with the very code of k_edge_in (same MFMA chain, same epilogue => same bits) into
+// T[(de_in + 2)][DE] bf16 rows in the stored word order, row de_in the all-zero input, row de_in + 1 the masked pair;
+// k_edge_in_tiles then writes E_h[b,i,j,:] = T[class(b,i,j)] with coalesced 16-byte stores: 28 B read + 2 DE B written
+// per pair and no arithmetic.
+template <int DE, int HE>
+__global__ void __launch_bounds__(64) k_edge_in_table(int de_in, const uint4* __restrict__ blob, uint4* __restrict__ T) {
+  using C = EdgeIoCfg<DE, HE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sW = reinterpret_cast<uint4*>(smem);
+  for (int t = threadIdx.x; t < (int)(C::IN_BYTES / 16); t += 64) sW[t] = blob[t];
+  float* sI = reinterpret_cast<float*>(smem + C::IN_BYTES);       // [32][de_in]: row r = one-hot(r) (zero for r >= de_in)
+  for (int t = threadIdx.x; t < 32 * de_in; t += 64) sI[t] = (t / de_in == t % de_in) ? 1.f : 0.f;
+  __syncthreads();
+  const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * 64;
+  const float* sP = reinterpret_cast<const float*>(sW + C::IN_FR * 64);
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  for (int pass = 0; pass < 2; ++pass) {               // pass 0: free pairs (pm = 1), pass 1: the masked pair (pm = 0)
+    const float pm = pass == 0 ? 1.f : 0.f;
+    f32x16 o[C::MT];
+    mlp_in_chain<DE, HE>(sI + r * de_in, de_in, h, lane, sW0, sW1, sP, o);
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int i2 = 0; i2 < 16; ++i2) { const float v = (o[mt][i2] + o[mt][i2]) * 0.5f * pm; o[mt][i2] = v; sum += v; }
+    sum = xhalf_sum(sum);
+    if (sum == 0.f && h == 0) o[0][0] = 1.f;
+    const int trow = pass == 0 ? r : de_in + 1;
+    const bool wr = pass == 0 ? r <= de_in : r == 0;
+#pragma unroll
+    for (int u = 0; u < C::KS1; ++u) {
+      const int mt = u >> 1, g0 = 2 * (u & 1);
+      uint4 st = {pack_bf16(o[mt][4 * g0 + 0], o[mt][4 * g0 + 1]), pack_bf16(o[mt][4 * g0 + 2], o[mt][4 * g0 + 3]),
+                  pack_bf16(o[mt][4 * g0 + 4], o[mt][4 * g0 + 5]), pack_bf16(o[mt][4 * g0 + 6], o[mt][4 * g0 + 7])};
+      row16_to_corder(st);
+      if (wr) T[trow * (DE / 8) + 2 * u + h] = st;
+    }
+  }
+}
+
+// One workgroup per pair of mirrored 32x32 tiles (it <= jt) of one graph.  Both tiles are read row-wise (coalesced) and met
+// in LDS; the workgroup (1) checks that they mirror each other bit for bit and that every pair is one-hot or all zero,
+// clearing flags[b] / flags[B + b] otherwise (all 2B flags must be 1 on entry), and (2) writes both output tiles from
+// the table as if the graph passed: k_edge_in, launched afterwards, rewrites the graphs whose flags were cleared.
+template <int DE>
+__global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__ E_in, int de_in, const uint8_t* __restrict__ nm,
+                                                       const uint4* __restrict__ T, uint4* __restrict__ E_out, int n,
+                                                       uint8_t* __restrict__ flags) {
+  constexpr int Q = DE / 8;                            // 16-byte words per pair
+  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z, B = gridDim.z;
   if (jt < it) return;
-  extern __shared__ float st[];                       // [32][32 * de_in] tile (it, jt), rows i, row-major
-  const int W = 32 * de_in;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sT = reinterpret_cast<uint4*>(smem);          // [(de_in + 2)][Q]
+  float* sA = reinterpret_cast<float*>(sT + 18 * Q);   // tile (it, jt): [32 rows i][32 * de_in]
+  __shared__ uint8_t cls[32][33];
+  const int W = 32 * de_in, W4 = W / 4;
   const float* base = E_in + (size_t)b * n * n * de_in;
-  for (int t = threadIdx.x; t < 32 * W; t += 256) {
-    const int ri = t / W, o = t - ri * W;
-    const int i = it * 32 + ri, j = jt * 32 + o / de_in;
-    st[t] = (i < n && j < n) ? base[((size_t)i * n + jt * 32) * de_in + o] : 0.f;
+  const bool vec = ((n * de_in) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_in) & 15) == 0;
+  for (int t = threadIdx.x; t < (de_in + 2) * Q; t += 256) sT[t] = T[t];
+  {
+    const int vw = min(32, n - jt * 32) * de_in;       // valid floats of a tile row
+    for (int t = threadIdx.x; t < 32 * W4; t += 256) {
+      const int ri = t / W4, o = (t - ri * W4) * 4, i = it * 32 + ri;
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < n) {
+        const float* p = base + ((size_t)i * n + jt * 32) * de_in + o;
+        if (vec && o + 4 <= vw) v = *reinterpret_cast<const float4*>(p);
+        else { if (o < vw) v.x = p[0]; if (o + 1 < vw) v.y = p[1]; if (o + 2 < vw) v.z = p[2]; if (o + 3 < vw) v.w = p[3]; }
+      }
+      *reinterpret_cast<float4*>(sA + ri * W + o) = v;
+    }
   }
   __syncthreads();
-  bool bad = false;
-  for (int t = threadIdx.x; t < 32 * W; t += 256) {   // tile (jt, it): rows j, columns i
-    const int rj = t / W, o = t - rj * W;
-    const int ci = o / de_in, c = o - ci * de_in;
-    const int j = jt * 32 + rj, i = it * 32 + ci;
-    if (i < n && j < n) bad = bad || (base[((size_t)j * n + it * 32) * de_in + o] != st[ci * W + rj * de_in + c]);
+  bool hot = true;
+  for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+    const int ri = t >> 5, cj = t & 31, i = it * 32 + ri, j = jt * 32 + cj;
+    int ones = 0, zeros = 0, c = de_in;
+    for (int k = 0; k < de_in; ++k) { const float v = sA[ri * W + cj * de_in + k]; ones += (v == 1.f); zeros += (v == 0.f); c = v != 0.f ? k : c; }
+    const bool in = i < n && j < n;
+    if (in) hot = hot && ((ones == 1 && zeros == de_in - 1) || zeros == de_in);
+    cls[ri][cj] = (in && i != j && nm[b * n + i] && nm[b * n + j]) ? c : de_in + 1;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) flags[b] = 0;
+  bool bad = false;
+  {
+    const int vw = min(32, n - it * 32) * de_in;
+    for (int t = threadIdx.x; t < 32 * W4; t += 256) {  // tile (jt, it): rows j, columns i
+      const int rj = t / W4, o = (t - rj * W4) * 4, j = jt * 32 + rj;
+      if (j >= n) continue;
+      const float* p = base + ((size_t)j * n + it * 32) * de_in + o;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec && o + 4 <= vw) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+      else for (int k = 0; k < 4; ++k) if (o + k < vw) v[k] = p[k];
+      for (int k = 0; k < 4; ++k) {
+        const int ci = (o + k) / de_in, c = (o + k) - ci * de_in;
+        if (o + k < vw) bad = bad || (v[k] != sA[ci * W + rj * de_in + c]);
+      }
+    }
+  }
+  const bool wave_bad = __any(bad), wave_cold = __any(!hot);       // wave-wide votes, taken before the lane-0 branch
+  if ((threadIdx.x & 63) == 0) {
+    if (wave_bad) flags[b] = 0;
+    if (wave_cold) flags[B + b] = 0;
+  }
+  __syncthreads();
+  const int p = threadIdx.x / Q, q = threadIdx.x % Q;  // Q = 8: 32 pairs x 8 words per pass
+  if (p < 32) {
+    for (int ri = 0; ri < 32; ++ri) {
+      const int i = it * 32 + ri, j = jt * 32 + p;
+      if (i < n && j < n) E_out[(((size_t)b * n + i) * n + j) * Q + q] = sT[cls[ri][p] * Q + q];
+    }
+    if (jt != it)
+      for (int rj = 0; rj < 32; ++rj) {
+        const int j = jt * 32 + rj, i = it * 32 + p;
+        if (i < n && j < n) E_out[(((size_t)b * n + j) * n + i) * Q + q] = sT[cls[p][rj] * Q + q];
+      }
+  }
 }
 
 // ---- output stage: logits E_o = sym((mlp_out_E(E_h) + E_in[..., :Ke]) * offdiag) (+ product->reactant skip) ------
@@ -280,16 +381,21 @@ __global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict
 #ifndef EXP_IOGRID_CAP
 #define EXP_IOGRID_CAP 2048
 #endif
+static inline size_t in_table_offset(int B) { return ((size_t)2 * B + 255) / 256 * 256; }
 static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
 
 template <int DE, int HE>
 static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s,
                      uint8_t* sym_flags = nullptr) {
   using C = EdgeIoCfg<DE, HE>;
-  if (sym_flags) {
-    if (hipMemsetAsync(sym_flags, 1, B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
+  if (sym_flags) {                                    // scratch: [B] symmetric, [B] one-hot, 16-byte aligned table
+    if (hipMemsetAsync(sym_flags, 1, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     const int nt = (n + 31) / 32;
-    k_edge_sym_flags<<<dim3(nt, nt, B), 256, 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, n, sym_flags);
+    uint4* T = reinterpret_cast<uint4*>(sym_flags + in_table_offset(B));
+    if (de_in <= 8) {
+      k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T);
+      k_edge_in_tiles<DE><<<dim3(nt, nt, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags);
+    } else if (hipMemsetAsync(sym_flags, 0, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
   }
   k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n, sym_flags);
   return DA_OK;
@@ -327,12 +433,20 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
   return DA_OK;
 }
 
-// da_edge_in with the symmetry of every input graph established beforehand by a coalesced pass (sym_flags: B bytes of
-// scratch the caller owns) instead of a transposed, uncoalesced read per pair.  Same result, bit for bit.
+// Scratch da_edge_in_sym needs: 2B flag bytes (symmetric, one-hot) + the (de_in + 2) x de bf16 table of the one-hot path.
+long long da_edge_in_scratch_bytes(int B, int de_in, int de) {
+  if (B < 0 || de_in < 1 || de_in > 16 || de < 8) return -1;
+  return (long long)in_table_offset(B) + (long long)(de_in + 2) * de * 2;
+}
+
+// da_edge_in with the symmetry and one-hotness of every input graph established beforehand by a coalesced pass
+// (sym_flags: da_edge_in_scratch_bytes() of scratch the caller owns, 256-byte aligned; on return its first B bytes say
+// which graphs are symmetric, the next B which are one-hot) instead of a transposed, uncoalesced read per pair.
+// Graphs that are both (every diffusion state) are written by a table gather.  Same result as da_edge_in, bit for bit.
 int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
                    int n, int de, int he, void* stream) {
   DA_CHECK_ARG(de_in >= 1 && de_in <= 16, "da_edge_in_sym: input edge feature width %d not in 1..16", de_in);
-  DA_CHECK_ARG(sym_flags != nullptr, "da_edge_in_sym: sym_flags scratch (B bytes) is null");
+  DA_CHECK_ARG(sym_flags != nullptr && ((uintptr_t)sym_flags & 15) == 0, "da_edge_in_sym: scratch is null or not 16-byte aligned");
   if (B == 0 || n == 0) return DA_OK;
   int rc;
   if (de == 64 && he == 128) rc = launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, sym_flags);

@@ -15,7 +15,7 @@ from . import pack
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
 TWO_PASS_EDGE_OUT = os.environ.get('DA_EDGE_OUT_2PASS', '1') != '0'   # da_edge_out_g + da_edge_out_finish instead of da_edge_out
-SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '0') == '1'   # y branch of every layer on a second HIP stream (measured: no gain, off)
+SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
 SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
@@ -107,18 +107,30 @@ def edge_stats(E_bf16, B, n, de):
     return st
 
 
-def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n):
+def film_buffers(pm: PackedModel, B, dev):
+    return (torch.empty(B, pm.dx, device=dev), torch.empty(B, pm.de, device=dev), torch.empty(B, pm.dx, device=dev),
+            torch.empty(B, pm.dx, device=dev))
+
+
+def layer_film(pm: PackedModel, lw: dict, y, B, out):
+    """FiLM vectors of a layer from y (layers.py:241-262): y_e_mul + 1, the per-graph e_out bias, y_x_add, y_x_mul + 1."""
+    ye2p1, ebias, yx1, yx2p1 = out
+    L.check(L.lib().da_y_film(L.ptr(y), lw['film'].arr, L.ptr(ye2p1), L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), _i(B), _i(pm.dy),
+                              _i(pm.dx), _i(pm.de), L.stream()), 'da_y_film')
+    return out
+
+
+def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None):
     """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
-    fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'."""
+    fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
+    `film`: the FiLM vectors if the caller computed them already (layer_film); `before_edge` / `after_edge`: hooks called
+    right before / after the edge kernel is enqueued (stream joins of the pipelined y branch)."""
     dev = X.device
     dx, de, dy = pm.dx, pm.de, pm.dy
     R = B * n
     lib = L.lib()
     S = L.stream()
-    ye2p1 = torch.empty(B, dx, device=dev); ebias = torch.empty(B, de, device=dev)
-    yx1 = torch.empty(B, dx, device=dev); yx2p1 = torch.empty(B, dx, device=dev)
-    L.check(lib.da_y_film(L.ptr(y), lw['film'].arr, L.ptr(ye2p1), L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), _i(B), _i(dy), _i(dx),
-                          _i(de), S), 'da_y_film')
+    ye2p1, ebias, yx1, yx2p1 = film if film is not None else layer_film(pm, lw, y, B, film_buffers(pm, B, dev))
     lib.da_kv_frag_bytes.restype = C.c_longlong
     kvf = torch.empty(lib.da_kv_frag_bytes(_i(B), _i(n), _i(dx)), dtype=torch.uint8, device=dev)
     if pm.fused_qkv:
@@ -136,6 +148,8 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n):
     nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(R, dx, device=dev)
+    if before_edge is not None:
+        before_edge()
     if PROFILE_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
     L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(ldq), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
@@ -145,6 +159,8 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n):
             'da_edge_layer')
     if PROFILE_EVENTS is not None:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
+    if after_edge is not None:
+        after_edge()
     X2 = torch.empty(B, n, dx, device=dev)
     if lw['xpost'] is not None:
         L.check(lib.da_x_post(L.ptr(newX_in), L.ptr(X), L.ptr(nm_u8), L.ptr(lw['xpost']), L.ptr(X2), _i(R), _i(dx), _i(pm.dffx), S),
@@ -164,19 +180,22 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n):
     return X2, E_out
 
 
+def node_stats(pm: PackedModel, X, B, n):
+    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=X.device)
+    L.check(L.lib().da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(pm.dx), _i(N_XSTAT_CHUNKS), L.stream()), 'da_x_stats')
+    return xst
+
+
+def y_update(pm: PackedModel, lw: dict, y, xst, estats, B, n, out):
+    L.check(L.lib().da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(out), _i(B), _i(n), _i(pm.dx),
+                                _i(pm.de), _i(pm.dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(N_STAT_CHUNKS), L.stream()), 'da_y_update')
+    return out
+
+
 def layer_y(pm: PackedModel, lw: dict, X, y, estats, B, n):
     """y branch of one XEyTransformerLayer (layers.py:277-281, 353-359): pooled statistics of the layer's INPUT X and E,
     y_out, the two LayerNorms and the y FFN.  Independent of the X / E branches of the same layer."""
-    dev = X.device
-    dx, de, dy = pm.dx, pm.de, pm.dy
-    lib = L.lib()
-    S = L.stream()
-    y2 = torch.empty(B, dy, device=dev)
-    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, dx, device=dev)
-    L.check(lib.da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(dx), _i(N_XSTAT_CHUNKS), S), 'da_x_stats')
-    L.check(lib.da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(y2), _i(B), _i(n), _i(dx),
-                            _i(de), _i(dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(N_STAT_CHUNKS), S), 'da_y_update')
-    return y2
+    return y_update(pm, lw, y, node_stats(pm, X, B, n), estats, B, n, torch.empty(B, pm.dy, device=X.device))
 
 
 def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
@@ -189,10 +208,11 @@ _SIDE = {}
 
 
 def _side_stream(dev):
-    """Optional second HIP stream for the y branch (DA_SIDE_STREAM=1).  Its pooled statistics are one HBM-bound pass over E
-    and its MLPs use 64 workgroups, so in principle they overlap the q/k/v and node-tail kernels of the X branch; measured
-    at B=64, n=300 in one box: 15.8 ms/step with the side stream, 15.6 without -- the edge kernel owns every CU's registers
-    and the statistics pass saturates HBM, there is nothing left to overlap.  Off by default."""
+    """Second HIP stream for the latency-bound tail of the y branch (DA_SIDE_STREAM=0 turns it off).  The pooled statistics
+    of a layer's input stay on the main stream (one HBM-bound pass; the edge kernel owns every CU's registers, nothing
+    overlaps with it).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
+    the edge kernel of layer l so that they run beside the node tail of layer l and the q/k/v and statistics passes of
+    layer l+1; the main stream joins right before the edge kernel of layer l+1."""
     if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
@@ -220,7 +240,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     pos = pos_encodings.contiguous().float() if pos_encodings is not None else None
     L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), S), 'da_x_in_finish')
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
-    sym_flags = torch.empty(B, dtype=torch.uint8, device=dev)
+    lib.da_edge_in_scratch_bytes.restype = C.c_longlong
+    sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
                                _i(pm.he), S), 'da_edge_in_sym')
     yh = torch.empty(B, pm.dy, device=dev)
@@ -228,20 +249,39 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
     # ---- layers
     main, side = torch.cuda.current_stream(), _side_stream(dev)
-    for lw in pm.layers:
-        if side is None:
+    if side is None:
+        for lw in pm.layers:
             st = edge_stats(Eh, B, n, pm.de)
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
-            continue
-        ready = main.record_event()                  # X, E, y of this layer are complete on the main stream
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            y_next = layer_y(pm, lw, Xh, yh, edge_stats(Eh, B, n, pm.de), B, n)
+    else:
+        # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
+        film = layer_film(pm, pm.layers[0], yh, B, film_buffers(pm, B, dev))
+        y_done = None
+        keep = []
+        for li, lw in enumerate(pm.layers):
+            st = edge_stats(Eh, B, n, pm.de); xst = node_stats(pm, Xh, B, n)
+            nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
+            y_next = torch.empty(B, pm.dy, device=dev)
+            film_next = film_buffers(pm, B, dev) if nxt is not None else None
+
+            def join(ev=y_done):
+                if ev is not None:
+                    main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
+
+            def fork(lw=lw, y=yh, st=st, xst=xst, y_next=y_next, nxt=nxt, film_next=film_next):
+                ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    y_update(pm, lw, y, xst, st, B, n, y_next)
+                    if nxt is not None:
+                        layer_film(pm, nxt, y_next, B, film_next)
+
+            X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork)
             y_done = side.record_event()
-        X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n)
-        main.wait_event(y_done)                      # also keeps Xh / Eh alive until the side stream has read them
-        y_next.record_stream(main)
-        Xh, Eh, yh = X_next, E_next, y_next
+            keep.append((yh, st, xst, film))
+            Xh, Eh, yh, film = X_next, E_next, y_next, film_next
+        main.wait_event(y_done)
+        del keep
     # ---- output stage
     h1 = torch.empty(R, pm.hx, device=dev)
     _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)

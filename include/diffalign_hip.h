@@ -132,8 +132,12 @@ int da_x_in_finish(float* X_h, const uint8_t* node_mask, const float* pos_encodi
 /* E_h(bf16) = encode_no_element(mask(sym(mlp_in_E(E))))  (transformer_model_with_y.py:657-661; 1 <= de_in <= 16). */
 int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
                int he, void* stream);
-/* da_edge_in with a per-graph symmetry pre-pass (coalesced 32x32 tile reads) instead of one transposed read per pair:
- * sym_flags = B bytes of caller-owned scratch.  Bit-identical to da_edge_in. */
+/* da_edge_in with a per-graph pre-pass (coalesced 32x32 tile reads) that establishes which graphs are symmetric and which
+ * are one-hot, instead of one transposed read per pair; graphs that are both (every diffusion state: helpers.py:743-745)
+ * (all-zero pairs allowed) are written by a gather from the (de_in + 2)-row table of the stage's possible results.  sym_flags = caller-owned scratch
+ * of da_edge_in_scratch_bytes(B, de_in, de) bytes, 16-byte aligned; on return bytes [0,B) = symmetric, [B,2B) = one-hot or zero.
+ * Bit-identical to da_edge_in. */
+long long da_edge_in_scratch_bytes(int B, int de_in, int de);
 int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
                    int n, int de, int he, void* stream);
 

@@ -54,6 +54,32 @@ def inputs(B, n, seed, P=None, dx=256):
     return X, zt['E'], y, zt['node_mask'], zt['atom_map_numbers'], pos, zt['mol_assignments']
 
 
+@pytest.mark.parametrize('n', [1, 5, 33, 45, 64, 97])
+def test_edge_in_table_path_shapes(n):
+    """da_edge_in_sym on symmetric one-hot graphs (table path, float4 and scalar tile loads, partial tiles, all-zero pairs)
+    against da_edge_in (MFMA path): bit-identical."""
+    from diffalign_amd import engine, _lib as L
+    hd = FULL['hidden_dims']
+    m, sd = build(FULL, 1, seed=7)
+    pm = m._pack(torch.device(D))
+    B = 4
+    g = torch.Generator().manual_seed(100 + n)
+    cl = torch.randint(0, KE, (B, n, n), generator=g)
+    cl = torch.triu(cl, 1); cl = cl + cl.transpose(1, 2)
+    E = F.one_hot(cl, KE).float()
+    nm = torch.rand(B, n, generator=g) < 0.8
+    E[3] = E[3] * (nm[3, :, None, None] & nm[3, None, :, None])            # graph 3: masked pairs all zero
+    E_d, nm_d = E.to(D), L.as_u8(nm.to(D))
+    L.lib().da_edge_in_scratch_bytes.restype = engine.C.c_longlong
+    scratch = torch.empty(int(L.lib().da_edge_in_scratch_bytes(engine._i(B), engine._i(KE), engine._i(hd['de']))), dtype=torch.uint8, device=D)
+    a_ = torch.empty(B, n, n, hd['de'], dtype=torch.bfloat16, device=D); b_ = torch.full_like(a_, 7.0)
+    args = (engine._i(B), engine._i(n), engine._i(hd['de']), engine._i(FULL['hidden_mlp_dims']['E']), L.stream())
+    L.check(L.lib().da_edge_in(L.ptr(E_d), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(a_), *args), 'edge_in')
+    L.check(L.lib().da_edge_in_sym(L.ptr(E_d), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(b_), L.ptr(scratch), *args), 'edge_in_sym')
+    assert torch.equal(a_, b_)
+    assert scratch[:2 * B].cpu().tolist() == [1] * (2 * B)
+
+
 @pytest.mark.parametrize('dims', [FULL, TINY], ids=['full', 'tiny'])
 def test_stages_vs_oracle(dims):
     """input stage, one layer, output stage -- each against the oracle on the same (bf16-rounded) inputs."""
@@ -88,16 +114,24 @@ def test_stages_vs_oracle(dims):
     assert torch.equal(Eh2, Eh2.transpose(1, 2))
     # -- da_edge_in_sym (symmetry established per graph by a coalesced pre-pass): bit-identical, on symmetric, non-symmetric and
     #    mixed batches (graph 1 made non-symmetric in a single entry)
+    #    Graphs that are symmetric AND one-hot take the table-gather path, all others the MFMA path: all five mixes below.
     Emix = E.clone(); Emix[1, 3, 5, 2] += 0.25
-    flags = torch.empty(B, dtype=torch.uint8, device=D)
-    for src_ in (E_d, Ea_d, Emix.to(D)):
+    Esym = ((Ea + Ea.transpose(1, 2)) / 2); Esym[2] = E[2]                  # symmetric, graphs 0 and 1 not one-hot
+    Ehot = E.clone(); Ehot[0, 2, 7] = Ehot[0, 2, 7].roll(1)                   # graph 0 one-hot but not symmetric
+    assert not torch.equal(Ehot, E)
+    L.lib().da_edge_in_scratch_bytes.restype = engine.C.c_longlong
+    flags = torch.empty(int(L.lib().da_edge_in_scratch_bytes(engine._i(B), engine._i(KE), engine._i(hd['de']))), dtype=torch.uint8, device=D)
+    seen = []
+    for src_ in (E_d, Ea_d, Emix.to(D), Esym.to(D), Ehot.to(D)):
         a_ = torch.empty_like(Eh); b_ = torch.empty_like(Eh)
         L.check(L.lib().da_edge_in(L.ptr(src_), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(a_), engine._i(B),
                                    engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in')
         L.check(L.lib().da_edge_in_sym(L.ptr(src_), engine._i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(b_), L.ptr(flags), engine._i(B),
                                        engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in_sym')
-        assert torch.equal(a_, b_)
-    assert flags.cpu().tolist() == [1, 0, 1]
+        bad = (a_ != b_).any(-1).nonzero()
+        assert bad.numel() == 0, (len(seen), flags[:2 * B].cpu().tolist(), bad[:8].tolist(), int(bad.shape[0]))
+        seen.append(flags[:2 * B].cpu().tolist())
+    assert seen == [[1, 1, 1, 1, 1, 1], [0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 1], [1, 1, 1, 0, 0, 1], [0, 1, 1, 1, 1, 1]], seen
     # -- one layer on random hidden features
     g = torch.Generator().manual_seed(3)
     Xh = torch.randn(B, n, hd['dx'], generator=g); yh = torch.randn(B, hd['dy'], generator=g)

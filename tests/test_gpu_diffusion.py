@@ -104,6 +104,10 @@ def test_posterior_probs_and_draws_golden(fam, t):
     mism_E = (zsE.argmax(-1).cpu().numpy() != z[k + 'zs_E']).mean()
     assert mism_X <= 1e-3 and mism_E <= 1e-4, (mism_X, mism_E)
     assert torch.equal(zsE, zsE.transpose(1, 2))
+    # the draw-only call (tile kernel: one evaluation per unordered pair) against the call that also returns probabilities
+    _, _, zsX2, zsE2 = helpers.posterior_sample(pred.X, pred.E, zt, tm.get_Qt(t_arr), tm.get_Qt_bar(t_arr - 1),
+                                                tm.get_Qt_bar(t_arr), noise=(qX, qE), want_prob=True)
+    assert torch.equal(zsX, zsX2) and torch.equal(zsE, zsE2)
 
 
 def test_fused_step_vs_oracle_full_size_properties():
@@ -131,6 +135,9 @@ def test_fused_step_vs_oracle_full_size_properties():
                                                   tm.get_Qt_bar(t_arr), noise=(qX.to(D), qE.to(D)), orig=orig,
                                                   node_masks=masks, want_prob=True)
     assert (gpX.cpu() - pX).abs().max() <= 2e-6 and (gpE.cpu() - pE).abs().max() <= 2e-6
+    _, _, tzX, tzE = helpers.posterior_sample(lX.to(D), lE.to(D), z, tm.get_Qt(t_arr), tm.get_Qt_bar(t_arr - 1),
+                                              tm.get_Qt_bar(t_arr), noise=(qX.to(D), qE.to(D)), orig=orig, node_masks=masks)
+    assert torch.equal(tzX, gzX) and torch.equal(tzE, gzE)         # draw-only tile kernel == per-pair kernel, bit for bit
     assert (gzX.cpu().argmax(-1) != zX.argmax(-1)).float().mean() <= 1e-3
     assert (gzE.cpu().argmax(-1) != zE.argmax(-1)).float().mean() <= 1e-4
     # properties: one-hot rows, symmetric E, condition (product side) untouched, idempotent apply_mask
