@@ -11,10 +11,11 @@ from .noise_schedule import (AbsorbingStateTransitionMaskNoEdge, DiscreteUniform
 from .placeholder import PlaceHolder
 from .elbo import ELBOMixin
 from .sampling import SamplingMixin
+from .training import TrainingMixin
 from .transformer_model_with_y import GraphTransformerWithY, GraphTransformerWithYAtomMapPosEmb
 
 
-class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, nn.Module):
+class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Module):
     def __init__(self, cfg, dataset_infos, node_type_counts_unnormalized=None, edge_type_counts_unnormalized=None,
                  use_data_parallel=None, device='cuda:0'):
         super().__init__()

@@ -222,8 +222,9 @@ def _side_stream(dev):
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
-                  use_skip=False):
-    """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713)."""
+                  use_skip=False, save: Optional[dict] = None):
+    """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
+    `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py)."""
     dev = X.device
     B, n = X.shape[:2]
     R = B * n
@@ -307,4 +308,6 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     else:
         L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B),
                                 _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out')
+    if save is not None:
+        save.update(X_in=X, E_in=E, X_hidden=Xh, out_X_hidden=h1, src=src, node_mask=nm)
     return Xo, Eo, yh

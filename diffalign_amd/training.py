@@ -1,0 +1,117 @@
+"""Training step (diffalign/diffusion/diffusion_abstract.py:134-225) -- the part that is built.
+
+Built: the forward of `training_step` through the HIP path (apply_noise, apply_mask, denoiser, the 'ce' / 'vb' / 'vbce'
+loss values) and the FIRST stage of the backward for the 'ce' loss: d loss / d logits (da_ce_grad) and, from it, the
+gradients of the output stage's last parameters (mlp_out_X.2, skip_scaling, skip_scaling_2).  Both are pinned to the
+reference: the loss values and the gradient norms `loss.backward()` leaves on those parameters are golden vectors
+(tests/golden/chain_elbo_tiny.npz).  NOT built: the backward through the transformer layers -- so there
+is no optimizer step yet and `training_backward_output_stage` says so in its name.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L, elbo as E_, graph
+from .placeholder import PlaceHolder
+
+
+def ce_grad(pred: PlaceHolder, dense_true: PlaceHolder, node_masks, lambda_E: float = 5.0, diffuse_nodes=True, diffuse_edges=True):
+    """d helpers.ce / d pred (helpers.py:153-191): what `loss.backward()` leaves in pred.X.grad / pred.E.grad."""
+    X, E = dense_true.X.contiguous().float(), dense_true.E.contiguous().float()
+    lX, lE = pred.X.contiguous().float(), pred.E.contiguous().float()
+    B, n, kx = X.shape
+    ke = E.shape[-1]
+    dev = X.device
+    mx, me = L.as_u8(node_masks[0]), L.as_u8(node_masks[1])
+    rows0X, rows0E = torch.zeros(B, n, device=dev), torch.zeros(B, n, n, device=dev)
+    sums = E_.masked_sums(rows0X, rows0E, node_masks)            # only the counts are used
+    gX, gE = torch.empty_like(lX), torch.empty_like(lE)
+    L.check(L.lib().da_ce_grad(L.ptr(X), L.ptr(E), L.ptr(lX), L.ptr(lE), L.ptr(mx), L.ptr(me), L.ptr(sums),
+                               C.c_float(1.0 if diffuse_nodes else 0.0), C.c_float(float(lambda_E) if diffuse_edges else 0.0),
+                               L.ptr(gX), L.ptr(gE), C.c_int(B), C.c_int(n), C.c_int(kx), C.c_int(ke), L.stream()), 'da_ce_grad')
+    return gX, gE
+
+
+class TrainingMixin:
+    """Needs from the host object: cfg, T, transition_model, dataset_info, model, forward, apply_noise, elbo_batch_quick."""
+
+    def training_step(self, data: PlaceHolder, i: int = 0, device=None, t_int: Optional[torch.Tensor] = None, noise=None,
+                      z_t: Optional[PlaceHolder] = None):
+        """diffusion_abstract.py:134-225.  `data`: dense PlaceHolder on the device (the reference's graph.to_dense is the data
+        loader's side).  Returns (loss_X, loss_E, loss) as the reference does -- values, without an autograd graph; the
+        context the backward needs stays in self._train_ctx.  t_int / noise / z_t fix the reference's random draws."""
+        d = self.cfg.diffusion
+        if getattr(d, 'classifier_free_guidance', False):
+            raise NotImplementedError('classifier-free guidance is off in both align_* experiments and is not built')
+        dense_data = data
+        B = dense_data.X.shape[0]
+        dev = dense_data.X.device
+        if t_int is None:
+            t_int = torch.randint(1, self.T + 1, size=(B, 1), device=dev)                                   # :136
+        node_masks = E_._node_masks(self, dense_data)
+        if z_t is None:
+            z_t, _ = self.apply_noise(dense_data, t_int=t_int, transition_model=self.transition_model, noise=noise)   # :137
+            z_t = graph.apply_mask(orig=dense_data, z_t=z_t, atom_decoder=self.dataset_info.atom_decoder,
+                                   bond_decoder=self.dataset_info.bond_decoder, mask_nodes=d.mask_nodes,
+                                   mask_edges=d.mask_edges, node_masks=node_masks)                            # :139-141
+        z_keep = z_t.get_new_object()                                                                         # :144
+        if not d.diffuse_edges: z_t.E = dense_data.E.clone()
+        if not d.diffuse_nodes: z_t.X = dense_data.X.clone()
+        saved: Dict[str, torch.Tensor] = {}
+        self.model._saved = saved
+        try:
+            with torch.no_grad():
+                pred = self.forward(z_t=z_t)                                                                  # :181-185
+        finally:
+            self.model._saved = None
+        lam = d.lambda_train[0]
+        loss_kind = getattr(getattr(self.cfg, 'train', None), 'loss', 'ce')
+        loss_X = loss_E = torch.zeros((1,))
+        if loss_kind in ('ce', 'vbce'):
+            rX, rE = E_.elbo_rows(E_.LOGP, dense_data, logits=pred)
+            s = E_.masked_sums(rX, rE, node_masks).double()
+            ce = (-(s[:, 0].sum() / s[:, 1].sum()) * float(bool(d.diffuse_nodes))
+                  - float(bool(d.diffuse_edges)) * lam * (s[:, 2].sum() / s[:, 3].sum())).float()          # helpers.py:186-189
+        if loss_kind == 'ce':
+            mx, me = node_masks[0].bool(), node_masks[1].bool()
+            loss_X, loss_E, loss = -rX[mx], -rE[me[:, :, None] & me[:, None, :]], ce
+        elif loss_kind == 'vb':
+            loss = self.elbo_batch_quick(dense_data, pred=pred, z_t=z_keep, lambda_E=lam)                     # :212
+        elif loss_kind == 'vbce':
+            loss = self.elbo_batch_quick(dense_data, pred=pred, z_t=z_keep, lambda_E=lam) + d.ce_lambda * ce  # :221-222
+        else:
+            raise ValueError(f'Unknown loss {loss_kind}')
+        self._train_ctx = dict(pred=pred, data=dense_data, node_masks=node_masks, saved=saved, loss_kind=loss_kind, lam=lam)
+        return loss_X, loss_E, loss
+
+    def training_backward_output_stage(self) -> Dict[str, torch.Tensor]:
+        """First stage of `loss.backward()` for train.loss == 'ce': gradients with respect to the logits and to the output
+        stage's last parameters.  Returns {'pred.X', 'pred.E', 'mlp_out_X.2.weight', 'mlp_out_X.2.bias', 'skip_scaling',
+        'skip_scaling_2'} (the skip entries only with the product->reactant skip connection).  The backward through
+        mlp_out_E, the transformer layers and the input stage is not built."""
+        ctx = getattr(self, '_train_ctx', None)
+        if ctx is None:
+            raise RuntimeError('training_backward_output_stage: call training_step first')
+        if ctx['loss_kind'] != 'ce':
+            raise NotImplementedError("only train.loss == 'ce' has a backward stage (d L_t / d logits of 'vb' is not built)")
+        d = self.cfg.diffusion
+        pred, data, saved = ctx['pred'], ctx['data'], ctx['saved']
+        gX, gE = ce_grad(pred, data, ctx['node_masks'], ctx['lam'], bool(d.diffuse_nodes), bool(d.diffuse_edges))
+        B, n, kx = gX.shape
+        ke = gE.shape[-1]
+        g2 = gX.reshape(B * n, kx)
+        out = {'pred.X': gX, 'pred.E': gE,
+               'mlp_out_X.2.weight': g2.t() @ saved['out_X_hidden'],       # (kx, hidden): a plain library GEMM
+               'mlp_out_X.2.bias': g2.sum(0)}
+        if saved.get('src') is not None:
+            part = torch.empty(B, 2, device=gX.device)
+            X_in, E_in = saved['X_in'], saved['E_in']
+            L.check(L.lib().da_skip_grad(L.ptr(gX), L.ptr(gE), L.ptr(X_in), C.c_int(X_in.shape[-1]), L.ptr(E_in), C.c_int(E_in.shape[-1]),
+                                         L.ptr(saved['src']), L.ptr(part), C.c_int(B), C.c_int(n), C.c_int(kx), C.c_int(ke),
+                                         L.stream()), 'da_skip_grad')
+            tot = part.double().sum(0).float()
+            out['skip_scaling'], out['skip_scaling_2'] = tot[0:1], tot[1:2]
+        return out

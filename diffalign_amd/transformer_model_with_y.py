@@ -33,6 +33,7 @@ class _DenoiserBase(nn.Module):
         self.mlp_out_y = mk(hidden_dims['dy'], hidden_mlp_dims['y'], output_dims['y'], False)   # unused by forward, kept for checkpoints
         self._packed = None
         self._packed_key = None
+        self._saved = None      # dict filled by engine.model_forward for the output-stage backward (training.py)
 
     def _pack(self, device):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -59,7 +60,7 @@ class GraphTransformerWithY(_DenoiserBase):
     def forward(self, X, E, y, node_mask):
         self._check(X)
         pm = self._pack(X.device)
-        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask)
+        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, save=self._saved)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask
 
@@ -88,6 +89,6 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
         self._check(X)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
-                                          use_skip=self.p_to_r_skip_connection)
+                                          use_skip=self.p_to_r_skip_connection, save=self._saved)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask

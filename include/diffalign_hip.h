@@ -94,6 +94,21 @@ int da_elbo_rows(int mode, const float* true_X, const float* true_E, const float
 int da_masked_sums(const float* rows_X, const float* rows_E, const uint8_t* mask_x, const uint8_t* mask_e, float* out, int B,
                    int n, void* stream);
 
+/* ---- training step, first stage of the backward (diffusion_abstract.py:134-225) ----------------------
+ * helpers.ce (utils/diffusion/helpers.py:153-191) backward: F.cross_entropy(mean) over the free rows gives
+ *   grad_X[r] = weight_X / #free nodes * (softmax(logits_X[r]) - onehot(argmax true_X[r]))  on free nodes, 0 elsewhere,
+ *   grad_E[p] = weight_E / #free pairs * (softmax(logits_E[p]) - onehot(argmax true_E[p]))  on free pairs, 0 elsewhere
+ * (weight_X = diffuse_nodes, weight_E = diffuse_edges * lambda_E), i.e. what loss.backward() leaves in pred.X.grad and
+ * pred.E.grad.  sums (B,4) is da_masked_sums' output (its counts are used); grad_X / grad_E may be NULL. */
+int da_ce_grad(const float* true_X, const float* true_E, const float* logits_X, const float* logits_E, const uint8_t* mask_x,
+               const uint8_t* mask_e, const float* sums, float weight_X, float weight_E, float* grad_X, float* grad_E, int B, int n,
+               int kx, int ke, void* stream);
+/* Gradients of skip_scaling and skip_scaling_2 (neuralnet/transformer_model_with_y.py:684-704, alignment 'correct') per
+ * graph: out (B,2); out[b][0] = sum over aligned nodes of <grad_X, X_in[src]> + sum over aligned pairs of
+ * <grad_E, E_in[src i, src j]>, out[b][1] = sum over non-aligned pairs of grad_E[..., 0].  src from da_align_index. */
+int da_skip_grad(const float* grad_X, const float* grad_E, const float* X_in, int dx_in, const float* E_in, int de_in, const int* src,
+                 float* out, int B, int n, int kx, int ke, void* stream);
+
 /* ---- L2 denoiser (graph transformer) -------------------------------------------------------------------------------
  * Hidden edge features travel between these calls as bf16 (B,n,n,de); node features X and globals y stay fp32.
  * Weights arrive pre-packed by diffalign_amd/pack.py: "blob" = MFMA fragments (1 KiB each, lane-linear, bf16) followed
