@@ -7,7 +7,7 @@ The reference does the same coarsely with SLURM array jobs over condition ranges
 slurm/slurm_sample.py:65-73) and duplicates every condition n_samples times (utils/graph.py:145-152)."""
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -58,3 +58,35 @@ def sample_sharded(n_conditions: int, n_samples: int, n_nodes: int,
         rs, re_ = shard_range(total, r, world)
         outX.append(Xs[r][:re_ - rs]); outE.append(Es[r][:re_ - rs])
     return torch.cat(outX, 0), torch.cat(outE, 0)
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
+    """Data-parallel training: average the ranks' gradients in place and return them.  The tensors are packed
+    in sorted-name order into flat fp32 buckets of <= bucket_bytes (the whole align_absorbing gradient is 32.7 MB: one or
+    two large ring all-reduces, which is what xGMI's per-link bound favours over many small ones), every bucket's
+    all-reduce is issued asynchronously before the first is waited for.  Every rank must pass the same names and shapes."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads
+    world = dist.get_world_size(group)
+    names = sorted(grads)
+    buckets, cur, cur_bytes = [], [], 0
+    for k in names:
+        nb = grads[k].numel() * 4
+        if cur and cur_bytes + nb > bucket_bytes:
+            buckets.append(cur); cur, cur_bytes = [], 0
+        cur.append(k); cur_bytes += nb
+    if cur:
+        buckets.append(cur)
+    flats, works = [], []
+    for ks in buckets:
+        flat = torch.cat([grads[k].detach().reshape(-1).float() for k in ks])
+        flats.append(flat)
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for ks, flat, w in zip(buckets, flats, works):
+        w.wait()
+        flat /= world
+        o = 0
+        for k in ks:
+            m = grads[k].numel()
+            grads[k].copy_(flat[o:o + m].reshape(grads[k].shape)); o += m
+    return grads

@@ -56,3 +56,36 @@ def test_two_rank_sharded_sampling_equals_single_rank(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     X, E = torch.load(out)
     assert torch.equal(X, ref[0]) and torch.equal(E, ref[1])
+
+
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from diffalign_amd.distributed import allreduce_gradients
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {'b.weight': torch.randn(7, 5, generator=g), 'a.bias': torch.randn(5, generator=g), 'c': torch.randn(1, generator=g),
+             'd.weight': torch.randn(33, 9, generator=g)}
+    res = allreduce_gradients(grads, bucket_bytes=160)           # several buckets, one tensor larger than a bucket
+    assert res is grads
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_is_the_mean(tmp_path):
+    from diffalign_amd.distributed import allreduce_gradients
+    per_rank = []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        per_rank.append({'b.weight': torch.randn(7, 5, generator=g), 'a.bias': torch.randn(5, generator=g), 'c': torch.randn(1, generator=g),
+                         'd.weight': torch.randn(33, 9, generator=g)})
+    single = {k: v.clone() for k, v in per_rank[0].items()}
+    assert all(torch.equal(v, per_rank[0][k]) for k, v in allreduce_gradients(single).items())   # world 1: unchanged
+    out = str(tmp_path / 'g.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    for k in per_rank[0]:
+        assert torch.allclose(res[k], (per_rank[0][k] + per_rank[1][k]) / 2, rtol=1e-6, atol=1e-7), k
