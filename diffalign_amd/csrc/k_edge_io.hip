@@ -247,14 +247,19 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
 }
 
 // ---- output stage: logits E_o = sym((mlp_out_E(E_h) + E_in[..., :Ke]) * offdiag) (+ product->reactant skip) ------
+template <int DE>
+__device__ __forceinline__ void edge_row_load(const bf16_t* __restrict__ erow, int h, uint4 (&v)[DE / 16]) {
+#pragma unroll
+  for (int u = 0; u < DE / 16; ++u) v[u] = *reinterpret_cast<const uint4*>(erow + 16 * u + 8 * h);
+}
 template <int DE, int HE>
-__device__ __forceinline__ void mlp_out_chain(const bf16_t* __restrict__ erow, int h, int lane, const uint4* sW0,
-                                              const uint4* sW1, const float* sP, f32x16& o) {
+__device__ __forceinline__ void mlp_out_chain_regs(const uint4 (&raw)[DE / 16], int h, int lane, const uint4* sW0,
+                                                   const uint4* sW1, const float* sP, f32x16& o) {
   using C = EdgeIoCfg<DE, HE>;
   bf16x8 eB[C::KS1];
 #pragma unroll
   for (int u = 0; u < C::KS1; ++u) {
-    uint4 v = *reinterpret_cast<const uint4*>(erow + 16 * u + 8 * h);
+    uint4 v = raw[u];
     row16_to_corder(v);
     eB[u] = frag_from_u4(v);
   }
@@ -272,6 +277,14 @@ __device__ __forceinline__ void mlp_out_chain(const bf16_t* __restrict__ erow, i
   load_bias16(o, sP + HE, h);
 #pragma unroll
   for (int s = 0; s < C::KSH; ++s) o = mfma32(lds_frag(sW1, s, lane), hB[s], o);
+}
+
+template <int DE, int HE>
+__device__ __forceinline__ void mlp_out_chain(const bf16_t* __restrict__ erow, int h, int lane, const uint4* sW0,
+                                              const uint4* sW1, const float* sP, f32x16& o) {
+  uint4 raw[DE / 16];
+  edge_row_load<DE>(erow, h, raw);
+  mlp_out_chain_regs<DE, HE>(raw, h, lane, sW0, sW1, sP, o);
 }
 
 template <int DE, int HE>
@@ -377,6 +390,150 @@ __global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict
   }
 }
 
+// ---- output stage in ONE pass over mirrored tiles: one workgroup per pair of 32x32 tiles (it <= jt) of one graph.
+//   phase 1  tile (jt, it), rows j:  sB[j][i] = mlp_out_E(E_h[b,j,i]) + E_in[b,j,i]        (LDS, 32 KiB)
+//   phase 2  tile (it, jt), rows i:  logits(i,j) = sym part + skip, written from registers; the symmetric part goes back
+//            into sB[j][i] in place (each element is read and rewritten by the same lane)
+//   phase 3  tile (jt, it) written row-wise from LDS (+ its own skip term); skipped on diagonal tiles
+// Every hidden edge row is read once, row-wise, and no intermediate reaches HBM.  Same arithmetic per element as
+// k_edge_out / k_edge_out_finish (a + b == b + a): bit-identical logits.
+#ifndef EXP_OUT_TILES_NW
+#define EXP_OUT_TILES_NW 8
+#endif
+constexpr int OT_NW = EXP_OUT_TILES_NW, OT_THR = 64 * OT_NW;   // waves / threads per workgroup of k_edge_out_tiles
+template <int DE, int HE>
+__global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
+                                                        const uint4* __restrict__ blob, const int* __restrict__ src,
+                                                        const float* __restrict__ s1p, const float* __restrict__ s2p,
+                                                        float* __restrict__ E_o, int n, int Ke) {
+  using C = EdgeIoCfg<DE, HE>;
+  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
+  if (jt < it) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* sW = reinterpret_cast<uint4*>(smem);
+  constexpr size_t WB = (C::OUT_BYTES + 15) / 16 * 16;
+  float* sB = reinterpret_cast<float*>(smem + WB);      // [32 rows j][32 columns i][8]
+  float* sRow = sB + 32 * 32 * 8;                       // [wave][32 * 8]: one output row of tile (it, jt) per wave
+  const bool vec4 = ((n * Ke) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_o) & 15) == 0;   // rows of E_o start 16-byte aligned
+  for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += OT_THR) sW[t] = blob[t];
+  __syncthreads();
+  const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * C::KS1 * 64;
+  const float* sP = reinterpret_cast<const float*>(sW + C::OUT_FR * 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const size_t gb = (size_t)b * n;
+  const float s1 = src ? s1p[0] : 0.f, s2 = src ? s2p[0] : 0.f;
+  __shared__ int sSrc[2][32];                           // alignment index of the tile's rows i ([0]) and j ([1]); -1: none
+  if (threadIdx.x < 64) {
+    const int w = threadIdx.x >> 5, q = (w ? jt : it) * 32 + (threadIdx.x & 31);
+    sSrc[w][threadIdx.x & 31] = (src && q < n) ? src[gb + q] : -1;
+  }
+  uint4 cur[DE / 16], nxt[DE / 16];
+  float ein_c[4], ein_n[4];                             // E_in[row, pair, 4h .. 4h+3] of the current / next row
+  auto load_ein = [&](int row, int col, float (&d)[4]) {
+    const float* p = E_in + ((gb + row) * n + col) * de_in + 4 * h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = (4 * h + e < Ke) ? p[e] : 0.f;
+  };
+  {
+    const int i = it * 32 + r, ic = i < n ? i : n - 1;
+    if (jt * 32 + wave < n) { edge_row_load<DE>(E_h + ((gb + jt * 32 + wave) * n + ic) * DE, h, cur); load_ein(jt * 32 + wave, ic, ein_c); }
+  }
+  for (int rj = wave; rj < 32; rj += OT_NW) {               // phase 1 (the next row's loads are issued before this row's MFMAs)
+    const int j = jt * 32 + rj;
+    if (j >= n) break;
+    const int i = it * 32 + r; const bool iv = i < n; const int ic = iv ? i : n - 1;
+    if (rj + OT_NW < 32 && j + OT_NW < n) { edge_row_load<DE>(E_h + ((gb + j + OT_NW) * n + ic) * DE, h, nxt); load_ein(j + OT_NW, ic, ein_n); }
+    f32x16 o;
+    mlp_out_chain_regs<DE, HE>(cur, h, lane, sW0, sW1, sP, o);
+    if (iv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int c = 4 * h + e; if (c < Ke) sB[(rj * 32 + r) * 8 + c] = o[e] + ein_c[e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < DE / 16; ++u) cur[u] = nxt[u];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ein_c[e] = ein_n[e];
+  }
+  __syncthreads();                                         // sSrc, sB complete
+  const int jA = jt * 32 + r; const bool jv = jA < n; const int jc = jv ? jA : n - 1;
+  const int sjA = sSrc[1][r];
+  float aln_c[4], aln_n[4];                             // E_in[src i, src j, 4h .. 4h+3] where the pair is aligned, else 0
+  auto load_aln = [&](int ri, float (&d)[4]) {
+    const int si = sSrc[0][ri];
+    const bool al = si >= 0 && sjA >= 0;
+    const float* p = E_in + ((gb + (al ? si : 0)) * n + (al ? sjA : 0)) * de_in + 4 * h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = (al && 4 * h + e < Ke) ? p[e] : 0.f;
+  };
+  if (it * 32 + wave < n) {
+    edge_row_load<DE>(E_h + ((gb + it * 32 + wave) * n + jc) * DE, h, cur); load_ein(it * 32 + wave, jc, ein_c);
+    if (src) load_aln(wave, aln_c);
+  }
+  for (int ri = wave; ri < 32; ri += OT_NW) {               // phase 2
+    const int i = it * 32 + ri;
+    if (i >= n) break;
+    if (ri + OT_NW < 32 && i + OT_NW < n) {
+      edge_row_load<DE>(E_h + ((gb + i + OT_NW) * n + jc) * DE, h, nxt); load_ein(i + OT_NW, jc, ein_n);
+      if (src) load_aln(ri + OT_NW, aln_n);
+    }
+    f32x16 o;
+    mlp_out_chain_regs<DE, HE>(cur, h, lane, sW0, sW1, sP, o);
+    float* srow = sRow + wave * 32 * 8;
+    if (jv) {
+      const bool aligned = sSrc[0][ri] >= 0 && sjA >= 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * h + e;
+        if (c >= Ke) continue;
+        float* m = sB + (r * 32 + ri) * 8 + c;          // (G + E_in)[b, j, i]
+        float v = (jA == i) ? 0.f : 0.5f * ((o[e] + ein_c[e]) + *m);
+        *m = v;
+        if (src) v += aligned ? s1 * aln_c[e] : (c == 0 ? s2 : 0.f);
+        srow[r * Ke + c] = v;                           // the row's 32 * Ke logits, contiguous as in memory
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DE / 16; ++u) cur[u] = nxt[u];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ein_c[e] = ein_n[e]; aln_c[e] = aln_n[e]; }
+    // one coalesced store of the row from the wave's LDS staging (same-wave LDS traffic is ordered: no barrier)
+    const int cnt = min(32, n - jt * 32) * Ke;
+    float* drow = E_o + ((gb + i) * n + jt * 32) * Ke;
+    if (vec4 && (cnt & 3) == 0) {
+      if (lane * 4 < cnt) *reinterpret_cast<float4*>(drow + lane * 4) = *reinterpret_cast<const float4*>(srow + lane * 4);
+    } else {
+      for (int t = lane; t < cnt; t += 64) drow[t] = srow[t];
+    }
+  }
+  if (jt == it) return;
+  __syncthreads();
+  // phase 3: rows j, columns i (contiguous floats of a tile row); the skip gathers of a batch are issued together
+  const int cntB = min(32, n - it * 32) * Ke, tot = 32 * 32 * Ke;
+  constexpr int UN = 7;
+  for (int t0 = threadIdx.x; t0 < tot; t0 += OT_THR * UN) {
+    float v[UN], g[UN]; bool ok[UN], al[UN]; size_t off[UN]; int cc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int t = t0 + u * OT_THR;
+      const int rj = t / (32 * Ke), o = t - rj * 32 * Ke, j = jt * 32 + rj;
+      ok[u] = t < tot && j < n && o < cntB;
+      const int ci = ok[u] ? o / Ke : 0, c = ok[u] ? o - ci * Ke : 0;
+      cc[u] = c;
+      v[u] = ok[u] ? sB[(rj * 32 + ci) * 8 + c] : 0.f;
+      const int sj = ok[u] ? sSrc[1][rj] : -1, si = sSrc[0][ci];
+      al[u] = sj >= 0 && si >= 0;
+      g[u] = al[u] ? E_in[((gb + sj) * n + si) * de_in + c] : 0.f;
+      off[u] = ((gb + j) * n + it * 32) * Ke + o;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      float x = v[u];
+      if (src) x += al[u] ? s1 * g[u] : (cc[u] == 0 ? s2 : 0.f);
+      if (ok[u]) E_o[off[u]] = x;
+    }
+  }
+}
+
 // ===================================================================================================
 #ifndef EXP_IOGRID_CAP
 #define EXP_IOGRID_CAP 2048
@@ -467,6 +624,25 @@ int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob,
   else if (de == 32 && he == 32) launch_out<32, 32>(E_h, E_in, de_in, blob, src, skip1, skip2, E_logits, B, n, ke, (hipStream_t)stream);
   else { da_set_error("da_edge_out: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_out");
+  return DA_OK;
+}
+
+// Output stage in one pass over mirrored 32x32 tiles (see k_edge_out_tiles); same arguments and result as da_edge_out.
+int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
+                      const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream) {
+  DA_CHECK_ARG(ke >= 1 && ke <= 8 && ke <= de_in, "da_edge_out_tiles: ke=%d must be in 1..8 and <= input width", ke);
+  DA_CHECK_ARG(!(src && (!skip1 || !skip2)), "da_edge_out_tiles: skip connection needs both scale pointers");
+  if (B == 0 || n == 0) return DA_OK;
+  const int nt = (n + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (de == 64 && he == 128)
+    k_edge_out_tiles<64, 128><<<dim3(nt, nt, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
+  else if (de == 32 && he == 32)
+    k_edge_out_tiles<32, 32><<<dim3(nt, nt, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
+  else { da_set_error("da_edge_out_tiles: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_out_tiles");
   return DA_OK;
 }
 

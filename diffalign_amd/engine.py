@@ -14,7 +14,7 @@ from . import pack
 
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
-TWO_PASS_EDGE_OUT = os.environ.get('DA_EDGE_OUT_2PASS', '1') != '0'   # da_edge_out_g + da_edge_out_finish instead of da_edge_out
+EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
 SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
 SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
@@ -300,7 +300,10 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     L.check(lib.da_x_out_finish(L.ptr(lin), _i(pm.kx), L.ptr(X), _i(pm.dx_in), L.ptr(src), L.ptr(s1), L.ptr(Xo), _i(B), _i(n),
                                 _i(pm.kx), S), 'da_x_out_finish')
     Eo = torch.empty(B, n, n, pm.ke, device=dev)
-    if TWO_PASS_EDGE_OUT:
+    if EDGE_OUT == 'tiles':
+        L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo),
+                                      _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')
+    elif EDGE_OUT == '2pass':
         G = torch.empty(B, n, n, 8, device=dev)
         L.check(lib.da_edge_out_g(L.ptr(Eh), L.ptr(pm.out_E), L.ptr(G), _i(B), _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_out_g')
         L.check(lib.da_edge_out_finish(L.ptr(G), L.ptr(E), _i(pm.de_in), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B), _i(n),

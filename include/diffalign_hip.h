@@ -214,6 +214,10 @@ int da_x_out_finish(const float* lin, int ldl, const float* X_in, int dx_in, con
 int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
                 const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream);
 
+/* da_edge_out in one pass over mirrored 32x32 tiles (every hidden edge row read once, row-wise; the mirrored tile meets
+ * its partner in LDS; no scratch).  Same arguments, bit-identical logits. */
+int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
+                      const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream);
 /* The same output stage in two passes, each hidden edge row read once and mlp_out_E evaluated once per ordered pair
  * (da_edge_out evaluates both orientations in one pass and reads the hidden tensor twice): G (B,n,n,8) fp32 is a scratch
  * the caller owns.  da_edge_out_g: G = mlp_out_E(E_h) (transformer_model_with_y.py:672-673); da_edge_out_finish:

@@ -171,6 +171,15 @@ def test_stages_vs_oracle(dims):
     L.check(L.lib().da_edge_out_finish(L.ptr(G), L.ptr(E_d), _i(KE), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo2), _i(B), _i(n), _i(KE),
                                        L.stream()), 'edge_out_finish')
     assert torch.equal(Eo2, Eo)
+    # the one-pass tile form (mirrored tiles meet in LDS; what the engine uses): bit-identical, with and without the skip
+    # connection, and on a NON-symmetric input edge tensor (the skip term of (j,i) is not the one of (i,j) then)
+    for src_, ein_ in ((src, E_d), (None, E_d), (src, Ea_d)):
+        a_ = torch.full_like(Eo, 9.0); b_ = torch.full_like(Eo, 7.0)
+        sk = (L.ptr(s1), L.ptr(s2)) if src_ is not None else (L.ptr(None), L.ptr(None))
+        for fn, dst in ((L.lib().da_edge_out, a_), (L.lib().da_edge_out_tiles, b_)):
+            L.check(fn(L.ptr(Eb), L.ptr(ein_), _i(KE), L.ptr(pm.out_E), L.ptr(src_), sk[0], sk[1], L.ptr(dst),
+                       _i(B), _i(n), _i(hd['de']), _i(dims['hidden_mlp_dims']['E']), _i(KE), L.stream()), 'edge_out')
+        assert torch.equal(a_, b_)
 
 
 def test_model_full_dims_one_layer_golden():
