@@ -168,14 +168,17 @@ __global__ void __launch_bounds__(64) k_edge_in_table(int de_in, const uint4* __
   }
 }
 
+constexpr int IN_HIST = 16;                          // ints per graph in the class histogram (de_in + 2 <= 10 used)
 // One workgroup per pair of mirrored 32x32 tiles (it <= jt) of one graph.  Both tiles are read row-wise (coalesced) and met
 // in LDS; the workgroup (1) checks that they mirror each other bit for bit and that every pair is one-hot or all zero,
-// clearing flags[b] / flags[B + b] otherwise (all 2B flags must be 1 on entry), and (2) writes both output tiles from
-// the table as if the graph passed: k_edge_in, launched afterwards, rewrites the graphs whose flags were cleared.
+// clearing flags[b] / flags[B + b] otherwise (all 2B flags must be 1 on entry), (2) writes both output tiles from
+// the table as if the graph passed: k_edge_in, launched afterwards, rewrites the graphs whose flags were cleared, and
+// (3) counts the graph's pairs per table row in hist[b][.] (zero on entry): the pooled statistics of the hidden tensor
+// follow from the counts and the table (k_e_stats_table) without another pass over it.
 template <int DE>
 __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__ E_in, int de_in, const uint8_t* __restrict__ nm,
                                                        const uint4* __restrict__ T, uint4* __restrict__ E_out, int n,
-                                                       uint8_t* __restrict__ flags) {
+                                                       uint8_t* __restrict__ flags, int* __restrict__ hist) {
   constexpr int Q = DE / 8;                            // 16-byte words per pair
   const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z, B = gridDim.z;
   if (jt < it) return;
@@ -183,6 +186,8 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
   uint4* sT = reinterpret_cast<uint4*>(smem);          // [(de_in + 2)][Q]
   float* sA = reinterpret_cast<float*>(sT + 18 * Q);   // tile (it, jt): [32 rows i][32 * de_in]
   __shared__ uint8_t cls[32][33];
+  __shared__ int sh[IN_HIST];                          // pairs of this tile (and its mirror) per table row
+  if (threadIdx.x < IN_HIST) sh[threadIdx.x] = 0;
   const int W = 32 * de_in, W4 = W / 4;
   const float* base = E_in + (size_t)b * n * n * de_in;
   const bool vec = ((n * de_in) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_in) & 15) == 0;
@@ -208,7 +213,9 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
     for (int k = 0; k < de_in; ++k) { const float v = sA[ri * W + cj * de_in + k]; ones += (v == 1.f); zeros += (v == 0.f); c = v != 0.f ? k : c; }
     const bool in = i < n && j < n;
     if (in) hot = hot && ((ones == 1 && zeros == de_in - 1) || zeros == de_in);
-    cls[ri][cj] = (in && i != j && nm[b * n + i] && nm[b * n + j]) ? c : de_in + 1;
+    const int k = (in && i != j && nm[b * n + i] && nm[b * n + j]) ? c : de_in + 1;
+    cls[ri][cj] = k;
+    if (in) atomicAdd(&sh[k], 1);
   }
   bool bad = false;
   {
@@ -232,6 +239,7 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
     if (wave_cold) flags[B + b] = 0;
   }
   __syncthreads();
+  if (threadIdx.x < de_in + 2 && sh[threadIdx.x]) atomicAdd(&hist[b * IN_HIST + threadIdx.x], sh[threadIdx.x] * (jt != it ? 2 : 1));
   const int p = threadIdx.x / Q, q = threadIdx.x % Q;  // Q = 8: 32 pairs x 8 words per pass
   if (p < 32) {
     for (int ri = 0; ri < 32; ++ri) {
@@ -243,6 +251,29 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
         const int j = jt * 32 + rj, i = it * 32 + p;
         if (i < n && j < n) E_out[(((size_t)b * n + j) * n + i) * Q + q] = sT[cls[p][rj] * Q + q];
       }
+  }
+}
+
+// Pooled statistics (k_e_stats' partials: sum, sum of squares, min, max per channel) of the hidden tensor of the graphs
+// that took the table path: out[b][0] from the class counts and the table, the other chunks neutral.  One block per graph.
+template <int DE>
+__global__ void __launch_bounds__(DE) k_e_stats_table(const uint8_t* __restrict__ flags, const bf16_t* __restrict__ T,
+                                                      const int* __restrict__ hist, int de_in, float* __restrict__ out, int B,
+                                                      int nchunk) {
+  const int b = blockIdx.x, ch = threadIdx.x;
+  if (!(flags[b] && flags[B + b])) return;             // k_e_stats reads this graph
+  double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+  for (int k = 0; k < de_in + 2; ++k) {
+    const int cnt = hist[b * IN_HIST + k];
+    if (!cnt) continue;
+    const float v = bf16_lo((unsigned)T[k * DE + ch]);
+    s += (double)cnt * v; q += (double)cnt * v * v; mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  float* o = out + (size_t)b * nchunk * 4 * DE;
+  o[ch] = (float)s; o[DE + ch] = (float)q; o[2 * DE + ch] = mn; o[3 * DE + ch] = mx;
+  for (int k = 1; k < nchunk; ++k) {
+    float* p = o + (size_t)k * 4 * DE;
+    p[ch] = 0.f; p[DE + ch] = 0.f; p[2 * DE + ch] = INFINITY; p[3 * DE + ch] = -INFINITY;
   }
 }
 
@@ -539,6 +570,7 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
 #define EXP_IOGRID_CAP 2048
 #endif
 static inline size_t in_table_offset(int B) { return ((size_t)2 * B + 255) / 256 * 256; }
+static inline size_t in_hist_offset(int B, int de_in, int de) { return (in_table_offset(B) + (size_t)(de_in + 2) * de * 2 + 255) / 256 * 256; }
 static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
 
 template <int DE, int HE>
@@ -549,9 +581,11 @@ static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void
     if (hipMemsetAsync(sym_flags, 1, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     const int nt = (n + 31) / 32;
     uint4* T = reinterpret_cast<uint4*>(sym_flags + in_table_offset(B));
+    int* hist = reinterpret_cast<int*>(sym_flags + in_hist_offset(B, de_in, DE));
+    if (hipMemsetAsync(hist, 0, (size_t)B * IN_HIST * sizeof(int), s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     if (de_in <= 8) {
       k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T);
-      k_edge_in_tiles<DE><<<dim3(nt, nt, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags);
+      k_edge_in_tiles<DE><<<dim3(nt, nt, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist);
     } else if (hipMemsetAsync(sym_flags, 0, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
   }
   k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n, sym_flags);
@@ -590,10 +624,25 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
   return DA_OK;
 }
 
-// Scratch da_edge_in_sym needs: 2B flag bytes (symmetric, one-hot) + the (de_in + 2) x de bf16 table of the one-hot path.
+// Scratch da_edge_in_sym needs: 2B flag bytes (symmetric, one-hot), the (de_in + 2) x de bf16 table of the one-hot path and
+// the per-graph class counts (16 ints).
 long long da_edge_in_scratch_bytes(int B, int de_in, int de) {
   if (B < 0 || de_in < 1 || de_in > 16 || de < 8) return -1;
-  return (long long)in_table_offset(B) + (long long)(de_in + 2) * de * 2;
+  return (long long)in_hist_offset(B, de_in, de) + (long long)B * IN_HIST * sizeof(int);
+}
+
+// Statistics partials (da_edge_stats' layout) of the graphs da_edge_in_sym served from its table, from the class counts it
+// left in `scratch`; returns in *skip the flag array to hand to da_edge_stats_skip for the other graphs.
+int da_edge_stats_table(const uint8_t* scratch, float* partials, int B, int de_in, int de, int nchunk, void* stream) {
+  DA_CHECK_ARG(scratch != nullptr && nchunk >= 1 && de_in >= 1 && de_in <= 8, "da_edge_stats_table: bad arguments");
+  if (B == 0) return DA_OK;
+  const bf16_t* T = reinterpret_cast<const bf16_t*>(scratch + in_table_offset(B));
+  const int* hist = reinterpret_cast<const int*>(scratch + in_hist_offset(B, de_in, de));
+  if (de == 64) k_e_stats_table<64><<<B, 64, 0, (hipStream_t)stream>>>(scratch, T, hist, de_in, partials, B, nchunk);
+  else if (de == 32) k_e_stats_table<32><<<B, 32, 0, (hipStream_t)stream>>>(scratch, T, hist, de_in, partials, B, nchunk);
+  else { da_set_error("da_edge_stats_table: de=%d not built (32, 64)", de); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_stats_table");
+  return DA_OK;
 }
 
 // da_edge_in with the symmetry and one-hotness of every input graph established beforehand by a coalesced pass

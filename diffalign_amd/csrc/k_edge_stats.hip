@@ -4,7 +4,7 @@
 // per-graph pooled statistics of the bf16 edge tensor (Etoy, neuralnet/layers.py:31-47): partial sums per chunk
 //   out[b][chunk][4][DE] = (sum, sum of squares, min, max) over the chunk's pairs (padding and diagonal included)
 template <int DE>
-__global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, int n, int nchunk) {
+__global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, int n, int nchunk, const uint8_t* skip) {
   constexpr int G = DE / 8;            // 16-byte groups per row
   constexpr int RL = 256 / G;          // rows handled concurrently
 #ifndef EXP_ESTATS_U
@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, in
 #else
   const int b = blockIdx.y, ch = blockIdx.x;
 #endif
+  if (skip && skip[b] && skip[gridDim.y + b]) return;  // graph served by da_edge_stats_table (flags of da_edge_in_sym)
   const size_t N = (size_t)n * n;
   const size_t per = (N + nchunk - 1) / nchunk;
   const size_t p0 = ch * per, p1 = min(N, p0 + per);
@@ -72,15 +73,24 @@ __global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, in
 
 extern "C" {
 
-int da_edge_stats(const void* E_bf16, float* partials, int B, int n, int de, int nchunk, void* stream) {
+static int edge_stats_launch(const void* E_bf16, float* partials, const uint8_t* skip, int B, int n, int de, int nchunk, void* stream) {
   DA_CHECK_ARG(nchunk >= 1, "da_edge_stats: nchunk < 1");
   if (B == 0 || n == 0) return DA_OK;
   dim3 grid(nchunk, B);
-  if (de == 64) k_e_stats<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
-  else if (de == 32) k_e_stats<32><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk);
+  if (de == 64) k_e_stats<64><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk, skip);
+  else if (de == 32) k_e_stats<32><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)E_bf16, partials, n, nchunk, skip);
   else { da_set_error("da_edge_stats: de=%d not built (32, 64)", de); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_stats");
   return DA_OK;
+}
+int da_edge_stats(const void* E_bf16, float* partials, int B, int n, int de, int nchunk, void* stream) {
+  return edge_stats_launch(E_bf16, partials, nullptr, B, n, de, nchunk, stream);
+}
+// da_edge_stats for the graphs whose two flags (skip[b], skip[B + b]: da_edge_in_sym's scratch) are not both set; the
+// partials of the others are left untouched (da_edge_stats_table writes them).
+int da_edge_stats_skip(const void* E_bf16, float* partials, const uint8_t* skip, int B, int n, int de, int nchunk, void* stream) {
+  DA_CHECK_ARG(skip != nullptr, "da_edge_stats_skip: skip flags are null");
+  return edge_stats_launch(E_bf16, partials, skip, B, n, de, nchunk, stream);
 }
 
 }  // extern "C"

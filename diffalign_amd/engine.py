@@ -120,6 +120,19 @@ def layer_film(pm: PackedModel, lw: dict, y, B, out):
     return out
 
 
+def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de):
+    """Statistics partials of the input stage's output: from the class counts da_edge_in_sym left in `scratch` for the graphs
+    its table served (no pass over the hidden tensor), da_edge_stats for the others."""
+    st = torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
+    lib = L.lib()
+    if de_in <= 8:
+        L.check(lib.da_edge_stats_table(L.ptr(scratch), L.ptr(st), _i(B), _i(de_in), _i(de), _i(N_STAT_CHUNKS), L.stream()),
+                'da_edge_stats_table')
+    L.check(lib.da_edge_stats_skip(L.ptr(E_bf16), L.ptr(st), L.ptr(scratch), _i(B), _i(n), _i(de), _i(N_STAT_CHUNKS), L.stream()),
+            'da_edge_stats_skip')
+    return st
+
+
 def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None):
     """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
     fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
@@ -250,9 +263,10 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
     # ---- layers
     main, side = torch.cuda.current_stream(), _side_stream(dev)
+    st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
     if side is None:
-        for lw in pm.layers:
-            st = edge_stats(Eh, B, n, pm.de)
+        for li, lw in enumerate(pm.layers):
+            st = st0 if li == 0 else edge_stats(Eh, B, n, pm.de)
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
     else:
         # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
@@ -260,7 +274,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         y_done = None
         keep = []
         for li, lw in enumerate(pm.layers):
-            st = edge_stats(Eh, B, n, pm.de); xst = node_stats(pm, Xh, B, n)
+            st = st0 if li == 0 else edge_stats(Eh, B, n, pm.de); xst = node_stats(pm, Xh, B, n)
             nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
             y_next = torch.empty(B, pm.dy, device=dev)
             film_next = film_buffers(pm, B, dev) if nxt is not None else None

@@ -155,6 +155,12 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
 long long da_edge_in_scratch_bytes(int B, int de_in, int de);
 int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
                    int n, int de, int he, void* stream);
+/* Etoy statistics of the stage's output without another pass over it: da_edge_stats_table writes da_edge_stats' partials
+ * for the graphs da_edge_in_sym served from its table (from the class counts it left in `scratch`), da_edge_stats_skip
+ * runs da_edge_stats on the other graphs only (skip = the same scratch).  Sums are exact products count x value instead of
+ * fp32 running sums: equal to da_edge_stats within fp32 rounding, not bit for bit. */
+int da_edge_stats_table(const uint8_t* scratch, float* partials, int B, int de_in, int de, int nchunk, void* stream);
+int da_edge_stats_skip(const void* E_bf16, float* partials, const uint8_t* skip, int B, int n, int de, int nchunk, void* stream);
 
 /* y_h = mlp_in_y(y)  (transformer_model_with_y.py:590-591), fp32. */
 int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, float* out, int B, int din,

@@ -130,6 +130,11 @@ def test_stages_vs_oracle(dims):
                                        engine._i(n), engine._i(hd['de']), engine._i(dims['hidden_mlp_dims']['E']), L.stream()), 'edge_in_sym')
         bad = (a_ != b_).any(-1).nonzero()
         assert bad.numel() == 0, (len(seen), flags[:2 * B].cpu().tolist(), bad[:8].tolist(), int(bad.shape[0]))
+        # pooled statistics of the stage's output: class counts x table for the graphs the table served, k_e_stats for the rest
+        fold = lambda st: torch.stack([st[:, :, 0].sum(1), st[:, :, 1].sum(1), st[:, :, 2].amin(1), st[:, :, 3].amax(1)], 1)
+        want, got = fold(engine.edge_stats(b_, B, n, hd['de'])), fold(engine.edge_stats_after_in(flags, b_, B, n, KE, hd['de']))
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-4), (len(seen), (got - want).abs().max().item())
+        assert torch.equal(got[:, 2:], want[:, 2:])
         seen.append(flags[:2 * B].cpu().tolist())
     assert seen == [[1, 1, 1, 1, 1, 1], [0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 1], [1, 1, 1, 0, 0, 1], [0, 1, 1, 1, 1, 1]], seen
     # -- one layer on random hidden features
