@@ -223,7 +223,7 @@ _SIDE = {}
 def _side_stream(dev):
     """Second HIP stream for the latency-bound tail of the y branch (DA_SIDE_STREAM=0 turns it off).  The pooled statistics
     of a layer's input stay on the main stream (one HBM-bound pass; the edge kernel owns every CU's registers, nothing
-    overlaps with it).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
+    overlaps with it; on a third stream, beside the node tail and the next q/k/v, it made the step 1-2 % slower).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
     the edge kernel of layer l so that they run beside the node tail of layer l and the q/k/v and statistics passes of
     layer l+1; the main stream joins right before the edge kernel of layer l+1."""
     if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
@@ -293,6 +293,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
 
             X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork)
             y_done = side.record_event()
+            keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
             keep.append((yh, st, xst, film))
             Xh, Eh, yh, film = X_next, E_next, y_next, film_next
         main.wait_event(y_done)
