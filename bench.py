@@ -206,12 +206,19 @@ def main():
             tj = json.load(f)
         if tj['workload'] == {'B': B, 'n': n}:
             traffic = tj['hbm_bytes_per_launch']
+            if engine.STATS_TAIL and 'with_stats_tail' in tj:   # layers >= 1 run the kernel with its statistics tail
+                nl = len(model.model.tf_layers)
+                traffic = (traffic + (nl - 1) * tj['with_stats_tail']['hbm_bytes_per_launch']) / nl
     except (OSError, KeyError, ValueError):
         pass
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
             'algorithmic_bytes_per_launch': bytes_launch, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
+    if engine.STATS_TAIL:
+        roof['note'] = ('launches of layers >= 1 include the Etoy statistics tail (da_edge_layer_stats: early-finishing waves stream '
+                        'E_in a second time, +0.74 GB and +0.06 ms per launch) that replaces a separate 0.155 ms pass; '
+                        'DA_STATS_TAIL=0 times the bare kernel')
     if rank == 0:
         out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,

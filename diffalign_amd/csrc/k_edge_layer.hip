@@ -83,6 +83,9 @@ struct EdgeLayerArgs {
   float* split;           // tail-split scratch [8][slots_per_xcd][3][DX] (running max, sum, weighted sum) or null
   int slots_per_xcd;
   int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
+  float* stats;           // Etoy statistics partials of E_in, k_e_stats' layout [B][stats_nchunk][4][DE], or null
+  int stats_nchunk;
+  int* ticket;            // work counter of the statistics tail (zero on entry)
 };
 
 // One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
@@ -579,6 +582,59 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     }
     STAMP(6)     // row end
   }
+  // ---- tail: pooled statistics of the INPUT tensor (Etoy of this layer, layers.py:31-47; k_e_stats' partials).  With static
+  // shares the older wave of every SIMD pair is done after ~80 % of the kernel's time; instead of leaving the SIMD to its
+  // partner alone it streams E_in once more, one (graph, chunk) ticket at a time, until the tickets run out -- the
+  // separate 737 MB statistics pass disappears behind the partner waves' latency-bound tail.
+  if (a.stats != nullptr) {
+    constexpr int G = DE / 8, RL = 64 / G, U = 8;      // lanes per pair row, rows per wave instruction, loads in flight
+    const size_t Np = (size_t)n * n;
+    const int nchunk = a.stats_nchunk, ntick = a.B * nchunk;
+    const size_t per = (Np + nchunk - 1) / nchunk;
+    const int g = lane % G, rl = lane / G;
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(a.ticket, 1);
+      t = __shfl(t, 0);
+      if (t >= ntick) break;
+      const int b = t / nchunk, ch = t - b * nchunk;
+      const size_t p0 = ch * per, p1 = min(Np, p0 + per);
+      float s[8], ss[8], mn[8], mx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; mn[e] = INFINITY; mx[e] = -INFINITY; }
+      auto fold = [&](const uint4& u) {
+        const unsigned d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
+          s[e] += v; ss[e] = fmaf(v, v, ss[e]); mn[e] = fminf(mn[e], v); mx[e] = fmaxf(mx[e], v);
+        }
+      };
+      const bf16_t* base = a.E_in + (size_t)b * Np * DE + 8 * g;
+      size_t p = p0 + rl;
+      for (; p + (U - 1) * RL < p1; p += U * RL) {
+        uint4 u[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) u[k] = *reinterpret_cast<const uint4*>(base + (p + k * RL) * DE);
+#pragma unroll
+        for (int k = 0; k < U; ++k) fold(u[k]);
+      }
+      for (; p < p1; p += RL) fold(*reinterpret_cast<const uint4*>(base + p * DE));
+#pragma unroll
+      for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[e] += __shfl_xor(s[e], off); ss[e] += __shfl_xor(ss[e], off);
+          mn[e] = fminf(mn[e], __shfl_xor(mn[e], off)); mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], off));
+        }
+      }
+      if (lane < G) {
+        float* o = a.stats + ((size_t)(b * nchunk + ch) * 4) * DE + 8 * lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = s[e]; o[DE + e] = ss[e]; o[2 * DE + e] = mn[e]; o[3 * DE + e] = mx[e]; }
+      }
+    }
+  }
 #ifdef EXP_STAMP
   if (lane == 0) {
     const int gw = blockIdx.x * NW + wave;
@@ -705,10 +761,10 @@ long long da_edge_split_scratch_bytes(int B, int n, int dx) {
   return (long long)8 * edge_max_rem(B * n, n) * NT * 3 * dx * (long long)sizeof(float);
 }
 
-int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
-                  const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
-                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
-                  long long split_scratch_bytes, void* stream) {
+static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                           const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                           const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                           long long split_scratch_bytes, float* stats, int stats_nchunk, int* ticket, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   if (B == 0 || n == 0) return DA_OK;
@@ -722,7 +778,8 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, stats, stats_nchunk, ticket};
+  if (stats && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { da_set_error("da_edge_layer_stats: memset failed"); return DA_ERR_HIP; }
   { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
     const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2); }
   int rc;
@@ -737,6 +794,26 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
     DA_CHECK_LAUNCH("da_edge_layer (split merge)");
   }
   return DA_OK;
+}
+
+int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                  const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                  const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                  long long split_scratch_bytes, void* stream) {
+  return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
+                         split_scratch, split_scratch_bytes, nullptr, 0, nullptr, stream);
+}
+
+// da_edge_layer that also leaves the Etoy statistics partials of E_in (da_edge_stats' layout, stats_nchunk chunks per graph)
+// in stats_partials: the waves that finish their share of the layer early compute them (see the kernel's tail).
+// ticket: 4 bytes of device scratch.
+int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                        const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                        const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                        long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, void* stream) {
+  DA_CHECK_ARG(stats_partials != nullptr && ticket != nullptr && stats_nchunk >= 1, "da_edge_layer_stats: statistics buffers are null");
+  return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
+                         split_scratch, split_scratch_bytes, stats_partials, stats_nchunk, ticket, stream);
 }
 
 }  // extern "C"

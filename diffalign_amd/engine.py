@@ -14,6 +14,8 @@ from . import pack
 
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
+N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
+STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
 SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
 SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
@@ -133,11 +135,12 @@ def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de):
     return st
 
 
-def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None):
+def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None, stats_out=None):
     """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
     fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
     `film`: the FiLM vectors if the caller computed them already (layer_film); `before_edge` / `after_edge`: hooks called
-    right before / after the edge kernel is enqueued (stream joins of the pipelined y branch)."""
+    right before / after the edge kernel is enqueued (stream joins of the pipelined y branch); `stats_out`: buffer
+    (B, N_TAIL_CHUNKS, 4, de) that receives the Etoy statistics partials of E_bf16 from the edge kernel's tail."""
     dev = X.device
     dx, de, dy = pm.dx, pm.de, pm.dy
     R = B * n
@@ -165,11 +168,15 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
         before_edge()
     if PROFILE_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
-    L.check(lib.da_edge_layer(L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(ldq), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
-                              L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
-                              C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
-                              L.ptr(split), C.c_longlong(split.numel() if split is not None else 0), S),
-            'da_edge_layer')
+    args = (L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(ldq), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
+            L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
+            C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
+            L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
+    if stats_out is not None:
+        ticket = torch.empty(1, dtype=torch.int32, device=dev)
+        L.check(lib.da_edge_layer_stats(*args, L.ptr(stats_out), _i(stats_out.shape[1]), L.ptr(ticket), S), 'da_edge_layer_stats')
+    else:
+        L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
     if PROFILE_EVENTS is not None:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
     if after_edge is not None:
@@ -201,7 +208,7 @@ def node_stats(pm: PackedModel, X, B, n):
 
 def y_update(pm: PackedModel, lw: dict, y, xst, estats, B, n, out):
     L.check(L.lib().da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(out), _i(B), _i(n), _i(pm.dx),
-                                _i(pm.de), _i(pm.dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(N_STAT_CHUNKS), L.stream()), 'da_y_update')
+                                _i(pm.de), _i(pm.dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(estats.shape[1]), L.stream()), 'da_y_update')
     return out
 
 
@@ -211,10 +218,18 @@ def layer_y(pm: PackedModel, lw: dict, X, y, estats, B, n):
     return y_update(pm, lw, y, node_stats(pm, X, B, n), estats, B, n, torch.empty(B, pm.dy, device=X.device))
 
 
+def tail_stats_buffer(pm: PackedModel, B, dev):
+    return torch.empty(B, N_TAIL_CHUNKS, 4, pm.de, dtype=torch.float32, device=dev)
+
+
 def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
-    """One XEyTransformerLayer (neuralnet/layers.py:330-361) on the current stream."""
-    X2, E_out = layer_main(pm, lw, X, E_bf16, y, nm_u8, B, n)
-    return X2, E_out, layer_y(pm, lw, X, y, estats, B, n)
+    """One XEyTransformerLayer (neuralnet/layers.py:330-361) on the current stream.  estats: Etoy statistics partials of
+    E_bf16, or None: the edge kernel's tail computes them (STATS_TAIL) or a separate pass does."""
+    tail = tail_stats_buffer(pm, B, X.device) if estats is None and STATS_TAIL else None
+    if estats is None and tail is None:
+        estats = edge_stats(E_bf16, B, n, pm.de)
+    X2, E_out = layer_main(pm, lw, X, E_bf16, y, nm_u8, B, n, stats_out=tail)
+    return X2, E_out, layer_y(pm, lw, X, y, estats if estats is not None else tail, B, n)
 
 
 _SIDE = {}
@@ -266,15 +281,16 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
     if side is None:
         for li, lw in enumerate(pm.layers):
-            st = st0 if li == 0 else edge_stats(Eh, B, n, pm.de)
-            Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st, B, n)
+            Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
         # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
         film = layer_film(pm, pm.layers[0], yh, B, film_buffers(pm, B, dev))
         y_done = None
         keep = []
         for li, lw in enumerate(pm.layers):
-            st = st0 if li == 0 else edge_stats(Eh, B, n, pm.de); xst = node_stats(pm, Xh, B, n)
+            tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
+            st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
+            xst = node_stats(pm, Xh, B, n)
             nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
             y_next = torch.empty(B, pm.dy, device=dev)
             film_next = film_buffers(pm, B, dev) if nxt is not None else None
@@ -291,7 +307,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                     if nxt is not None:
                         layer_film(pm, nxt, y_next, B, film_next)
 
-            X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork)
+            X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork, stats_out=tail)
             y_done = side.record_event()
             keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
             keep.append((yh, st, xst, film))

@@ -149,6 +149,14 @@ def test_stages_vs_oracle(dims):
     Xh_d, yh_d = Xh.to(D).contiguous(), yh.to(D).contiguous()
     gX, gE, gy = engine.layer_forward(pm, pm.layers[0], Xh_d, Eb, yh_d, nm_d, st, B, n)
     torch.cuda.synchronize()
+    # the same layer with the Etoy statistics computed by the edge kernel's tail (da_edge_layer_stats) instead of a separate pass
+    tail = engine.tail_stats_buffer(pm, B, Eb.device).fill_(float('nan'))
+    tX, tE = engine.layer_main(pm, pm.layers[0], Xh_d, Eb, yh_d, nm_d, B, n, stats_out=tail)
+    assert torch.equal(tX, gX) and torch.equal(tE, gE)
+    fold = lambda t_: torch.stack([t_[:, :, 0].double().sum(1), t_[:, :, 1].double().sum(1), t_[:, :, 2].double().amin(1), t_[:, :, 3].double().amax(1)], 1)
+    assert torch.allclose(fold(tail), fold(st), rtol=1e-5, atol=1e-4) and torch.equal(fold(tail)[:, 2:], fold(st)[:, 2:])
+    _, _, ty = engine.layer_forward(pm, pm.layers[0], Xh_d, Eb, yh_d, nm_d, None, B, n)
+    assert torch.allclose(ty, gy, rtol=1e-4, atol=1e-5)
     assert rel_l2(gy, oy) <= 2e-2, rel_l2(gy, oy)
     assert rel_l2(gX, oX) <= 2e-2, rel_l2(gX, oX)
     assert rel_l2(gE.float(), oE) <= 2e-2, rel_l2(gE.float(), oE)

@@ -1,4 +1,5 @@
-"""Micro-benchmark of da_edge_layer alone (for rocprofv3 --pmc passes).  python tools/bench_edge.py [B] [n] [iters]"""
+"""Micro-benchmark of da_edge_layer alone (for rocprofv3 --pmc passes).  python tools/bench_edge.py [B] [n] [iters] [tail]
+(tail: da_edge_layer_stats, the Etoy statistics computed by the kernel's tail)"""
 import os, sys, math, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +22,7 @@ X = torch.randn(B, n, 256, device=D, generator=g)
 E = torch.randn(B, n, n, 64, device=D, generator=g).to(torch.bfloat16)
 y = torch.randn(B, 64, device=D, generator=g)
 nm = torch.ones(B, n, dtype=torch.uint8, device=D)
-st = engine.edge_stats(E, B, n, 64)
+st = None if (len(sys.argv) > 4 and sys.argv[4] == 'tail') else engine.edge_stats(E, B, n, 64)
 for _ in range(2):
     engine.layer_forward(pm, pm.layers[0], X, E, y, nm, st, B, n)
 torch.cuda.synchronize()
