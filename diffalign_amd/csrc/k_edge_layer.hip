@@ -83,6 +83,7 @@ struct EdgeLayerArgs {
   float* split;           // tail-split scratch [8][slots_per_xcd][3][DX] (running max, sum, weighted sum) or null
   int slots_per_xcd;
   int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
+  int skew;               // the older half of a workgroup's waves takes `skew` whole rows more, the younger half as many fewer
   float* stats;           // Etoy statistics partials of E_in, k_e_stats' layout [B][stats_nchunk][4][DE], or null
   int stats_nchunk;
   int* ticket;            // work counter of the statistics tail (zero on entry)
@@ -102,6 +103,9 @@ struct EdgeLayerArgs {
 // that every wave gets the same amount of work (at B*n = 19,200 rows and 2,048 waves the incomplete round would keep
 // 37 % of the waves busy for a full row time).  A run leaves its online-softmax state in the scratch; k_edge_split_merge
 // folds the runs of a row.  Both kernels (and the host sizing) use this one definition.
+// The whole rows are not shared out evenly: the older half of a workgroup's waves (one of every SIMD pair) takes `skew` rows
+// more and the younger half as many fewer, because the older wave of a pair wins the issue arbitration and would otherwise
+// finish at ~80 % of the kernel's time (EdgeLayerArgs::skew; 11 / 7 rows instead of 9 / 9 at the benchmark size: -3 %).
 // (Handing the units out dynamically inside a workgroup, by a ticket counter in LDS, was measured and is 7 % SLOWER:
 // with static shares the older wave of each SIMD pair wins the issue arbitration, finishes its share in 80 % of the time
 // and leaves its partner a stretch alone; balanced pairs that stay in step get less out of the SIMD than that.)
@@ -336,8 +340,13 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const EdgePart part(R, gridDim.x, NW, NT, xcd, a.split != nullptr);
   const int wid = bi * NW + wave;
-  int kfull = 0;
+  int kfull = 0, kextra = 0;
   int u0 = wid * part.tpw, u1 = min(part.rem * NT, u0 + part.tpw);
+  // uneven static shares: the wave that was launched first on a SIMD wins the issue arbitration against its partner, so it is
+  // given more rows -- `nfc` common rounds, then 2 * skew half-rounds for the older half of the waves only
+  const int skew = min(a.skew, part.nfull), nfc = part.nfull - skew;
+  const bool older = wave < NW / 2;
+  const int oidx = bi * (NW / 2) + wave;
 
   if (wave >= NW / 2) {
     if (a.prio) __builtin_amdgcn_s_setprio(1);
@@ -353,8 +362,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #endif
   for (;;) {
     int row, jt0, jt1, slot = -1;
-    if (kfull < part.nfull) {
+    if (kfull < nfc) {
       row = part.row_begin + kfull * part.W + wid; jt0 = 0; jt1 = NT; ++kfull;
+      if (row >= part.row_end) continue;
+    } else if (older && kextra < 2 * skew) {
+      row = part.row_begin + nfc * part.W + kextra * (part.W / 2) + oidx; jt0 = 0; jt1 = NT; ++kextra;
       if (row >= part.row_end) continue;
     } else if (u0 < u1) {
       const int rl = u0 / NT;
@@ -778,10 +790,13 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, stats, stats_nchunk, ticket};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, stats, stats_nchunk, ticket};
   if (stats && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { da_set_error("da_edge_layer_stats: memset failed"); return DA_ERR_HIP; }
   { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
-    const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2); }
+    const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2);
+    // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
+    if (edge_threads() == 512) a.skew = (int)(0.22f * EdgePart(rows, grid, 8, NT, 0, split != nullptr).nfull + 0.3f);
+    const char* e3 = getenv("DA_EDGE_SKEW"); if (e3) a.skew = atoi(e3); }
   int rc;
   if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
   else if (de == 32 && dx == 64 && dff == 64) rc = launch_edge<32, 64, 64>(a, grid, (hipStream_t)stream);
