@@ -84,6 +84,7 @@ struct EdgeLayerArgs {
   int slots_per_xcd;
   int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
   int skew;               // the older half of a workgroup's waves takes `skew` whole rows more, the younger half as many fewer
+  int tail_old;           // the runs of the split rows all go to the older half
   float* stats;           // Etoy statistics partials of E_in, k_e_stats' layout [B][stats_nchunk][4][DE], or null
   int stats_nchunk;
   int* ticket;            // work counter of the statistics tail (zero on entry)
@@ -105,13 +106,14 @@ struct EdgeLayerArgs {
 // folds the runs of a row.  Both kernels (and the host sizing) use this one definition.
 // The whole rows are not shared out evenly: the older half of a workgroup's waves (one of every SIMD pair) takes `skew` rows
 // more and the younger half as many fewer, because the older wave of a pair wins the issue arbitration and would otherwise
-// finish at ~80 % of the kernel's time (EdgeLayerArgs::skew; 11 / 7 rows instead of 9 / 9 at the benchmark size: -3 %).
+// finish at ~80 % of the kernel's time (EdgeLayerArgs::skew and tail_old; 107.5 / 80 tiles instead of 93.75 / 93.75 at the
+// benchmark size).
 // (Handing the units out dynamically inside a workgroup, by a ticket counter in LDS, was measured and is 7 % SLOWER:
 // with static shares the older wave of each SIMD pair wins the issue arbitration, finishes its share in 80 % of the time
 // and leaves its partner a stretch alone; balanced pairs that stay in step get less out of the SIMD than that.)
 struct EdgePart {
   int row_begin, row_end, W, nfull, rem, tpw;
-  __host__ __device__ EdgePart(int R, int grid_blocks, int NW, int NT, int xcd, bool split) {
+  __host__ __device__ EdgePart(int R, int grid_blocks, int NW, int NT, int xcd, bool split, bool tail_old = false) {
     const int chunk = (R + 7) / 8;
     row_begin = xcd * chunk; row_end = row_begin + chunk < R ? row_begin + chunk : R;
     if (row_end < row_begin) row_end = row_begin;
@@ -119,7 +121,8 @@ struct EdgePart {
     const int rows = row_end - row_begin;
     nfull = split ? rows / W : (rows + W - 1) / W;
     rem = split ? rows - nfull * W : 0;
-    tpw = rem > 0 ? (rem * NT + W - 1) / W : 0;
+    const int Wt = tail_old ? W / 2 : W;               // waves that take runs of the split rows (tail_old: the older half only)
+    tpw = rem > 0 ? (rem * NT + Wt - 1) / Wt : 0;
   }
 };
 
@@ -338,15 +341,16 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 
   // XCD-aware persistent walk over work units (EdgePart): whole rows, then runs of key tiles of the split rows
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const EdgePart part(R, gridDim.x, NW, NT, xcd, a.split != nullptr);
+  const EdgePart part(R, gridDim.x, NW, NT, xcd, a.split != nullptr, a.tail_old != 0);
   const int wid = bi * NW + wave;
   int kfull = 0, kextra = 0;
-  int u0 = wid * part.tpw, u1 = min(part.rem * NT, u0 + part.tpw);
   // uneven static shares: the wave that was launched first on a SIMD wins the issue arbitration against its partner, so it is
   // given more rows -- `nfc` common rounds, then 2 * skew half-rounds for the older half of the waves only
   const int skew = min(a.skew, part.nfull), nfc = part.nfull - skew;
   const bool older = wave < NW / 2;
   const int oidx = bi * (NW / 2) + wave;
+  const int tw = a.tail_old ? (older ? oidx : -1) : wid;   // index among the waves that take runs of the split rows
+  int u0 = tw < 0 ? 0 : tw * part.tpw, u1 = tw < 0 ? 0 : min(part.rem * NT, u0 + part.tpw);
 
   if (wave >= NW / 2) {
     if (a.prio) __builtin_amdgcn_s_setprio(1);
@@ -659,10 +663,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 
 // folds the runs of every split row (EdgePart) into the x_out input: newX_in = yx1 + yx2p1 * (sum_r a_r e^{m_r-M}) / (sum_r l_r e^{m_r-M})
 __global__ void __launch_bounds__(256) k_edge_split_merge(const float* split, int slots_per_xcd, const float* yx1, const float* yx2p1,
-                                                          float* newX_in, int R, int n, int DX, int grid_blocks, int NW, int max_rem) {
+                                                          float* newX_in, int R, int n, int DX, int grid_blocks, int NW, int max_rem,
+                                                          int tail_old) {
   const int NT = (n + 31) / 32;
   const int xcd = blockIdx.x / max_rem, rl = blockIdx.x % max_rem;
-  const EdgePart part(R, grid_blocks, NW, NT, xcd, true);
+  const EdgePart part(R, grid_blocks, NW, NT, xcd, true, tail_old != 0);
   if (rl >= part.rem) return;
   const int row = part.row_begin + part.nfull * part.W + rl;
   const int b = row / n;
@@ -790,13 +795,26 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, stats, stats_nchunk, ticket};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, stats, stats_nchunk, ticket};
   if (stats && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { da_set_error("da_edge_layer_stats: memset failed"); return DA_ERR_HIP; }
   { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
     const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2);
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
-    if (edge_threads() == 512) a.skew = (int)(0.22f * EdgePart(rows, grid, 8, NT, 0, split != nullptr).nfull + 0.3f);
-    const char* e3 = getenv("DA_EDGE_SKEW"); if (e3) a.skew = atoi(e3); }
+    // default shares: ~57 % of a SIMD pair's tiles to the older wave (the per-slot run times of the EXP_STAMP build cross there:
+    // older 2067 + 209 s, younger 2595 - 162 s k-cycles for s rows of skew at 9 rows per wave), from whole rows of skew plus,
+    // optionally, all runs of the split rows
+    if (edge_threads() == 512) {
+      const EdgePart p0(rows, grid, 8, NT, 0, split != nullptr);
+      const float tail_rows = p0.W > 0 ? (float)p0.rem / p0.W : 0.f, pair = 2.f * (p0.nfull + tail_rows);
+      float best = 1e9f;
+      for (int to = 0; to <= (split ? 1 : 0); ++to)
+        for (int sk = 0; sk <= p0.nfull; ++sk) {
+          const float d = fabsf((p0.nfull + sk + (to ? 2.f : 1.f) * tail_rows) / pair - 0.575f);
+          if (d < best) { best = d; a.skew = sk; a.tail_old = to; }
+        }
+    }
+    const char* e3 = getenv("DA_EDGE_SKEW"); if (e3) a.skew = atoi(e3);
+    const char* e4 = getenv("DA_EDGE_TAIL_OLD"); if (e4) a.tail_old = atoi(e4); }
   int rc;
   if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
   else if (de == 32 && dx == 64 && dff == 64) rc = launch_edge<32, 64, 64>(a, grid, (hipStream_t)stream);
@@ -805,7 +823,7 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
   DA_CHECK_LAUNCH("da_edge_layer");
   if (split) {
     k_edge_split_merge<<<8 * max_rem, 256, 0, (hipStream_t)stream>>>(split, max_rem * NT, yx1, yx2p1, newX_in, rows, n, dx, grid,
-                                                                    edge_threads() / 64, max_rem);
+                                                                    edge_threads() / 64, max_rem, a.tail_old);
     DA_CHECK_LAUNCH("da_edge_layer (split merge)");
   }
   return DA_OK;
