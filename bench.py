@@ -104,7 +104,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--extra-features', choices=['inputs', 'device'], default='inputs',
                     help="'inputs' (default, SURVEY §8d: the 8 + 12 extra features are given); 'device': computed inside the step "
-                         '(csrc/k_extra.hip + torch.linalg.eigh), as a real sampling loop does')
+                         '(csrc/k_extra.hip + the batched partial eigensolver of csrc/k_extra_eig.hip), as a real sampling loop does')
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
