@@ -428,10 +428,7 @@ __global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict
 //   phase 3  tile (jt, it) written row-wise from LDS (+ its own skip term); skipped on diagonal tiles
 // Every hidden edge row is read once, row-wise, and no intermediate reaches HBM.  Same arithmetic per element as
 // k_edge_out / k_edge_out_finish (a + b == b + a): bit-identical logits.
-#ifndef EXP_OUT_TILES_NW
-#define EXP_OUT_TILES_NW 8
-#endif
-constexpr int OT_NW = EXP_OUT_TILES_NW, OT_THR = 64 * OT_NW;   // waves / threads per workgroup of k_edge_out_tiles
+constexpr int OT_NW = 8, OT_THR = 64 * OT_NW;   // waves / threads per workgroup of k_edge_out_tiles (4 and 16 measured: slower)
 template <int DE, int HE>
 __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
                                                         const uint4* __restrict__ blob, const int* __restrict__ src,

@@ -7,15 +7,8 @@ template <int DE>
 __global__ void __launch_bounds__(256) k_e_stats(const bf16_t* E, float* out, int n, int nchunk, const uint8_t* skip) {
   constexpr int G = DE / 8;            // 16-byte groups per row
   constexpr int RL = 256 / G;          // rows handled concurrently
-#ifndef EXP_ESTATS_U
-#define EXP_ESTATS_U 4
-#endif
-  constexpr int U = EXP_ESTATS_U;      // independent 16-byte loads in flight per thread
-#ifdef EXP_ESTATS_REV
-  const int b = gridDim.y - 1 - blockIdx.y, ch = gridDim.x - 1 - blockIdx.x;
-#else
+  constexpr int U = 4;                 // independent 16-byte loads in flight per thread (2, 8, 16 measured: no faster)
   const int b = blockIdx.y, ch = blockIdx.x;
-#endif
   if (skip && skip[b] && skip[gridDim.y + b]) return;  // graph served by da_edge_stats_table (flags of da_edge_in_sym)
   const size_t N = (size_t)n * n;
   const size_t per = (N + nchunk - 1) / nchunk;
