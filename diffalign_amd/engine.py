@@ -200,8 +200,8 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
     return X2, E_out
 
 
-def node_stats(pm: PackedModel, X, B, n):
-    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=X.device)
+def node_stats(pm: PackedModel, X, B, n, out=None):
+    xst = out if out is not None else torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=X.device)
     L.check(L.lib().da_x_stats(L.ptr(X), L.ptr(xst), _i(B), _i(n), _i(pm.dx), _i(N_XSTAT_CHUNKS), L.stream()), 'da_x_stats')
     return xst
 
@@ -290,7 +290,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
             st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
-            xst = node_stats(pm, Xh, B, n)
+            xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)   # filled on the side stream (Xtoy statistics of Xh)
             nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
             y_next = torch.empty(B, pm.dy, device=dev)
             film_next = film_buffers(pm, B, dev) if nxt is not None else None
@@ -299,10 +299,11 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                 if ev is not None:
                     main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
 
-            def fork(lw=lw, y=yh, st=st, xst=xst, y_next=y_next, nxt=nxt, film_next=film_next):
+            def fork(lw=lw, X=Xh, y=yh, st=st, xst=xst, y_next=y_next, nxt=nxt, film_next=film_next):
                 ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
+                    node_stats(pm, X, B, n, out=xst)
                     y_update(pm, lw, y, xst, st, B, n, y_next)
                     if nxt is not None:
                         layer_film(pm, nxt, y_next, B, film_next)
@@ -310,7 +311,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork, stats_out=tail)
             y_done = side.record_event()
             keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
-            keep.append((yh, st, xst, film))
+            keep.append((Xh, yh, st, xst, film))
             Xh, Eh, yh, film = X_next, E_next, y_next, film_next
         main.wait_event(y_done)
         del keep
