@@ -17,20 +17,21 @@ struct XPostCfg {
   static constexpr size_t BLOB_BYTES = (size_t)N_FR * 1024 + (size_t)N_PAR * 4;
 };
 
+constexpr int XP_WPB = 1;   // waves per workgroup: 600 one-wave workgroups spread over all CUs (35.6 us); 4 waves on 150 CUs: 40.1 us
 template <int DX, int DFF>
-__global__ void __launch_bounds__(256) k_x_post(const float* __restrict__ newX_in, const float* __restrict__ X,
+__global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict__ newX_in, const float* __restrict__ X,
                                                 const uint8_t* __restrict__ mask, const uint4* __restrict__ blob,
                                                 float* __restrict__ out, int R) {
   using C = XPostCfg<DX, DFF>;
   __shared__ __attribute__((aligned(16))) float sP[C::N_PAR];
   {
     const float* gp = reinterpret_cast<const float*>(blob + (size_t)C::N_FR * 64);
-    for (int t = threadIdx.x; t < C::N_PAR; t += 256) sP[t] = gp[t];
+    for (int t = threadIdx.x; t < C::N_PAR; t += 64 * XP_WPB) sP[t] = gp[t];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  const int m0 = (blockIdx.x * XP_WPB + wave) * 32;
   if (m0 >= R) return;
   const int row = min(m0 + r, R - 1);
   const bool rvalid = m0 + r < R;
@@ -165,10 +166,10 @@ int da_x_post(const float* newX_in, const float* X, const uint8_t* node_mask, co
   DA_CHECK_ARG(rows >= 0, "da_x_post: negative size");
   DA_CHECK_ARG(X != X_out && newX_in != X_out, "da_x_post: in-place not supported");
   if (rows == 0) return DA_OK;
-  const int grid = (rows + 127) / 128;
+  const int grid = (rows + 32 * XP_WPB - 1) / (32 * XP_WPB);
   hipStream_t s = (hipStream_t)stream;
-  if (dx == 256 && dffx == 256) k_x_post<256, 256><<<grid, 256, 0, s>>>(newX_in, X, node_mask, (const uint4*)blob, X_out, rows);
-  else if (dx == 64 && dffx == 64) k_x_post<64, 64><<<grid, 256, 0, s>>>(newX_in, X, node_mask, (const uint4*)blob, X_out, rows);
+  if (dx == 256 && dffx == 256) k_x_post<256, 256><<<grid, 64 * XP_WPB, 0, s>>>(newX_in, X, node_mask, (const uint4*)blob, X_out, rows);
+  else if (dx == 64 && dffx == 64) k_x_post<64, 64><<<grid, 64 * XP_WPB, 0, s>>>(newX_in, X, node_mask, (const uint4*)blob, X_out, rows);
   else { da_set_error("da_x_post: dims (dx=%d, dffX=%d) not built; built: (256,256), (64,64)", dx, dffx); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_x_post");
   return DA_OK;
