@@ -4,6 +4,7 @@
 // lane).  Replaces da_linear (59 MB of fp32 q|k|v written) + da_kv_pack (39 MB read back).
 #include "mfma_util.h"
 
+constexpr int QKV_PARTS = 3;   // waves per key tile: one per projection (38 -> 32 us; 6: 39 us, 12: 59 us)
 template <int DX>
 __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X, const uint4* __restrict__ W,
                                                      const float* __restrict__ bias, const uint8_t* __restrict__ mask,
@@ -12,8 +13,11 @@ __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int NT = (n + 31) / 32;
-  const int gw = blockIdx.x * 4 + wave;
-  if (gw >= B * NT) return;
+  // one wave = one key tile (b, jt) and ONE of the three projections (1,800 waves at the benchmark size instead of 600:
+  // the kernel is bound by the latency of a single wave's weight stream, not by the re-read of the 32 activation rows)
+  const int gwp = blockIdx.x * 4 + wave;
+  if (gwp >= QKV_PARTS * B * NT) return;
+  const int part = gwp % QKV_PARTS, gw = gwp / QKV_PARTS;
   const int b = gw / NT, jt = gw - b * NT;
   const float* ap = X + ((size_t)b * n + min(32 * jt + r, n - 1)) * DX + 8 * h;
   bf16x8 af[KS];
@@ -66,12 +70,14 @@ __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X
     }
   };
   uint4 wA[KS], wB[KS];
-  load_w(wA, 0);
-  for (int t = 0; t < 3 * NCB; t += 2) {
+  constexpr int TPW = 3 * NCB / QKV_PARTS;             // column tiles per wave
+  const int t0 = part * TPW, t1 = t0 + TPW;
+  load_w(wA, t0);
+  for (int t = t0; t < t1; t += 2) {
     load_w(wB, t + 1);
     tile(wA, t);
     load_w(wA, t + 2);
-    if (t + 1 < 3 * NCB) tile(wB, t + 1);
+    if (t + 1 < t1) tile(wB, t + 1);
   }
 }
 
@@ -84,7 +90,7 @@ int da_qkv_frag(const float* X, const void* W_bf16, const float* bias, const uin
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_qkv_frag: negative size");
   if (B == 0 || n == 0) return DA_OK;
   const int NT = (n + 31) / 32;
-  const int grid = (B * NT + 3) / 4;
+  const int grid = (QKV_PARTS * B * NT + 3) / 4;
   hipStream_t s = (hipStream_t)stream;
   if (dx == 256) k_qkv_frag<256><<<grid, 256, 0, s>>>(X, (const uint4*)W_bf16, bias, node_mask, Q, (uint4*)kv_frag, B, n);
   else if (dx == 64) k_qkv_frag<64><<<grid, 256, 0, s>>>(X, (const uint4*)W_bf16, bias, node_mask, Q, (uint4*)kv_frag, B, n);
