@@ -48,3 +48,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16(f, 0
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, ((unsigned)b) << 16); }
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// (it, jt), it <= jt: the idx-th pair of mirrored tiles, row-major over the upper triangle of an nt x nt tile grid
+// (grids of nt (nt + 1) / 2 workgroups instead of nt x nt with the lower half exiting at once)
+__device__ __forceinline__ void tri_tile(int idx, int nt, int& it, int& jt) {
+  it = 0;
+  while (idx >= nt - it) { idx -= nt - it; ++it; }
+  jt = it + idx;
+}

@@ -296,8 +296,9 @@ __global__ void __launch_bounds__(256) k_posterior_E_tiles(const float* __restri
                                                            const float* __restrict__ Qsb, const float* __restrict__ Qtb, float temp,
                                                            const float* __restrict__ noise, const float* __restrict__ orig,
                                                            const uint8_t* __restrict__ me, float* __restrict__ zs_out, int n) {
-  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
-  if (jt < it) return;
+  int it, jt;
+  tri_tile(blockIdx.x, (n + 31) / 32, it, jt);
+  const int b = blockIdx.y;
   __shared__ float sM[K * K * K];
   __shared__ uint8_t cls[32][33];
   {
@@ -430,7 +431,7 @@ static int launch_post_E(const float* logits, const float* zt, const uint8_t* nm
   if constexpr (K <= 8) {
     if (!prob && zs) {
       const int nt = cdiv(n, 32);
-      k_posterior_E_tiles<K><<<dim3(nt, nt, B), 256, 0, s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, me, zs, n);
+      k_posterior_E_tiles<K><<<dim3(nt * (nt + 1) / 2, B), 256, 0, s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, me, zs, n);
       return 0;
     }
   }

@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
                                                        const uint4* __restrict__ T, uint4* __restrict__ E_out, int n,
                                                        uint8_t* __restrict__ flags, int* __restrict__ hist) {
   constexpr int Q = DE / 8;                            // 16-byte words per pair
-  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z, B = gridDim.z;
-  if (jt < it) return;
+  int it, jt;
+  tri_tile(blockIdx.x, (n + 31) / 32, it, jt);
+  const int b = blockIdx.y, B = gridDim.y;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sT = reinterpret_cast<uint4*>(smem);          // [(de_in + 2)][Q]
   float* sA = reinterpret_cast<float*>(sT + 18 * Q);   // tile (it, jt): [32 rows i][32 * de_in]
@@ -435,8 +436,9 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
                                                         const float* __restrict__ s1p, const float* __restrict__ s2p,
                                                         float* __restrict__ E_o, int n, int Ke) {
   using C = EdgeIoCfg<DE, HE>;
-  const int it = blockIdx.x, jt = blockIdx.y, b = blockIdx.z;
-  if (jt < it) return;
+  int it, jt;
+  tri_tile(blockIdx.x, (n + 31) / 32, it, jt);
+  const int b = blockIdx.y;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sW = reinterpret_cast<uint4*>(smem);
   constexpr size_t WB = (C::OUT_BYTES + 15) / 16 * 16;
@@ -582,7 +584,7 @@ static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void
     if (hipMemsetAsync(hist, 0, (size_t)B * IN_HIST * sizeof(int), s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     if (de_in <= 8) {
       k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T);
-      k_edge_in_tiles<DE><<<dim3(nt, nt, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist);
+      k_edge_in_tiles<DE><<<dim3(nt * (nt + 1) / 2, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist);
     } else if (hipMemsetAsync(sym_flags, 0, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
   }
   k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n, sym_flags);
@@ -682,10 +684,10 @@ int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void*
   const int nt = (n + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   if (de == 64 && he == 128)
-    k_edge_out_tiles<64, 128><<<dim3(nt, nt, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+    k_edge_out_tiles<64, 128><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
         (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
   else if (de == 32 && he == 32)
-    k_edge_out_tiles<32, 32><<<dim3(nt, nt, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+    k_edge_out_tiles<32, 32><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
         (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
   else { da_set_error("da_edge_out_tiles: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_out_tiles");
