@@ -240,12 +240,13 @@ def _side_stream(dev):
     of a layer's input stay on the main stream (one HBM-bound pass; the edge kernel owns every CU's registers, nothing
     overlaps with it; on a third stream, beside the node tail and the next q/k/v, it made the step 1-2 % slower).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
     the edge kernel of layer l so that they run beside the node tail of layer l and the q/k/v and statistics passes of
-    layer l+1; the main stream joins right before the edge kernel of layer l+1."""
+    layer l+1; the main stream joins right before the edge kernel of layer l+1.  The Xtoy statistics (13 us) get a stream
+    of their own beside q/k/v.  Returns (y stream, statistics stream) or None."""
     if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        _SIDE[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
     return _SIDE[key]
 
 
@@ -277,7 +278,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
     # ---- layers
-    main, side = torch.cuda.current_stream(), _side_stream(dev)
+    main, sides = torch.cuda.current_stream(), _side_stream(dev)
+    side, side2 = sides if sides is not None else (None, None)
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
     if side is None:
         for li, lw in enumerate(pm.layers):
@@ -290,7 +292,12 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
             st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
-            xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)   # filled on the side stream (Xtoy statistics of Xh)
+            xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
+            x_ready = main.record_event()            # Xh is complete: its Xtoy statistics run beside q/k/v on a stream of their own
+            with torch.cuda.stream(side2):               # (on the y stream they lengthen the chain the next edge kernel waits for: +0.12 ms/step)
+                side2.wait_event(x_ready)
+                node_stats(pm, Xh, B, n, out=xst)
+                xs_done = side2.record_event()
             nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
             y_next = torch.empty(B, pm.dy, device=dev)
             film_next = film_buffers(pm, B, dev) if nxt is not None else None
@@ -299,11 +306,11 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                 if ev is not None:
                     main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
 
-            def fork(lw=lw, X=Xh, y=yh, st=st, xst=xst, y_next=y_next, nxt=nxt, film_next=film_next):
+            def fork(lw=lw, y=yh, st=st, xst=xst, xs_done=xs_done, y_next=y_next, nxt=nxt, film_next=film_next):
                 ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    node_stats(pm, X, B, n, out=xst)
+                    side.wait_event(xs_done)
                     y_update(pm, lw, y, xst, st, B, n, y_next)
                     if nxt is not None:
                         layer_film(pm, nxt, y_next, B, film_next)
