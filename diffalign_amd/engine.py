@@ -262,13 +262,36 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     X = X.contiguous().float(); E = E.contiguous().float(); y = y.contiguous().float()
     assert X.shape[-1] == pm.dx_in and E.shape[-1] == pm.de_in and y.shape[-1] == pm.dy_in, 'input feature widths'
     nm = L.as_u8(node_mask)
-    # ---- input stage
+    main, sides = torch.cuda.current_stream(), _side_stream(dev)
+    side, side2 = sides if sides is not None else (None, None)
+    # ---- input stage.  The node path (two linears, positional encodings, the alignment index of the skip connection) depends
+    # on the inputs only: with side streams it runs beside the edge input stage.
     h0 = torch.empty(R, pm.hx, device=dev)
-    _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
     Xh = torch.empty(B, n, pm.dx, device=dev)
-    _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
     pos = pos_encodings.contiguous().float() if pos_encodings is not None else None
-    L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), S), 'da_x_in_finish')
+    src = None
+    if use_skip:
+        assert pm.skip is not None and atom_map_numbers is not None and mol_assignments is not None
+        src = torch.empty(B, n, dtype=torch.int32, device=dev)
+        am64, mol64 = atom_map_numbers.contiguous(), mol_assignments.contiguous()
+
+    def node_input_path():
+        _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
+        _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
+        L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), L.stream()), 'da_x_in_finish')
+        if use_skip:
+            L.check(lib.da_align_index(L.ptr(am64, torch.int64), L.ptr(mol64, torch.int64), L.ptr(src), _i(B), _i(n), L.stream()),
+                    'da_align_index')
+
+    xin_done = None
+    if side2 is None:
+        node_input_path()
+    else:
+        in_ready = main.record_event()
+        with torch.cuda.stream(side2):
+            side2.wait_event(in_ready)
+            node_input_path()
+            xin_done = side2.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
     lib.da_edge_in_scratch_bytes.restype = C.c_longlong
     sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
@@ -277,9 +300,9 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     yh = torch.empty(B, pm.dy, device=dev)
     L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
                         _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
+    if xin_done is not None:
+        main.wait_event(xin_done)
     # ---- layers
-    main, sides = torch.cuda.current_stream(), _side_stream(dev)
-    side, side2 = sides if sides is not None else (None, None)
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
     if side is None:
         for li, lw in enumerate(pm.layers):
@@ -322,22 +345,27 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             Xh, Eh, yh, film = X_next, E_next, y_next, film_next
         main.wait_event(y_done)
         del keep
-    # ---- output stage
+    # ---- output stage (the node output path beside the edge output stage)
     h1 = torch.empty(R, pm.hx, device=dev)
-    _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)
     lin = torch.empty(R, pm.kx, device=dev)
-    _linear(h1, pm.hx, pm.out_X[2], pm.out_X[3], None, lin, pm.kx, R, pm.kx, pm.hx, False)
-    src = None
-    s1 = s2 = None
-    if use_skip:
-        assert pm.skip is not None and atom_map_numbers is not None and mol_assignments is not None
-        src = torch.empty(B, n, dtype=torch.int32, device=dev)
-        L.check(lib.da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
-                                   L.ptr(src), _i(B), _i(n), S), 'da_align_index')
-        s1, s2 = pm.skip
     Xo = torch.empty(B, n, pm.kx, device=dev)
-    L.check(lib.da_x_out_finish(L.ptr(lin), _i(pm.kx), L.ptr(X), _i(pm.dx_in), L.ptr(src), L.ptr(s1), L.ptr(Xo), _i(B), _i(n),
-                                _i(pm.kx), S), 'da_x_out_finish')
+    s1, s2 = pm.skip if use_skip else (None, None)
+
+    def node_output_path():
+        _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)
+        _linear(h1, pm.hx, pm.out_X[2], pm.out_X[3], None, lin, pm.kx, R, pm.kx, pm.hx, False)
+        L.check(lib.da_x_out_finish(L.ptr(lin), _i(pm.kx), L.ptr(X), _i(pm.dx_in), L.ptr(src), L.ptr(s1), L.ptr(Xo), _i(B), _i(n),
+                                    _i(pm.kx), L.stream()), 'da_x_out_finish')
+
+    xout_done = None
+    if side2 is None:
+        node_output_path()
+    else:
+        xh_ready = main.record_event()
+        with torch.cuda.stream(side2):
+            side2.wait_event(xh_ready)
+            node_output_path()
+            xout_done = side2.record_event()
     Eo = torch.empty(B, n, n, pm.ke, device=dev)
     if EDGE_OUT == 'tiles':
         L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo),
@@ -350,6 +378,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     else:
         L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B),
                                 _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out')
+    if xout_done is not None:
+        main.wait_event(xout_done)
     if save is not None:
         save.update(X_in=X, E_in=E, X_hidden=Xh, out_X_hidden=h1, src=src, node_mask=nm)
     return Xo, Eo, yh
