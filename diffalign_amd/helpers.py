@@ -42,12 +42,33 @@ def posterior_sample(pred_X, pred_E, z_t: PlaceHolder, Qt: PlaceHolder, Qsb: Pla
         oX, oE = f(orig.X), f(orig.E)
         mx, me = L.as_u8(node_masks[0]), L.as_u8(node_masks[1])
     tabs = [f(Qt.X), f(Qsb.X), f(Qtb.X), f(Qt.E), f(Qsb.E), f(Qtb.E)]
-    L.check(L.lib().da_posterior_sample(
-        L.ptr(pX), L.ptr(pE), L.ptr(ztX), L.ptr(ztE), L.ptr(L.as_u8(z_t.node_mask)),
-        *[L.ptr(t) for t in tabs], C.c_float(temperature[0]), C.c_float(temperature[1]),
-        L.ptr(qX), L.ptr(qE), L.ptr(oX), L.ptr(oE), L.ptr(mx), L.ptr(me),
-        L.ptr(probX), L.ptr(probE), L.ptr(zsX), L.ptr(zsE),
-        C.c_int(B), C.c_int(n), C.c_int(kx), C.c_int(ke), L.stream()), 'da_posterior_sample')
+    nm = L.as_u8(z_t.node_mask)
+
+    def launch(node_part, edge_part):
+        n_ = (lambda t: t) if node_part else (lambda t: None)
+        e_ = (lambda t: t) if edge_part else (lambda t: None)
+        L.check(L.lib().da_posterior_sample(
+            L.ptr(pX), L.ptr(pE), L.ptr(ztX), L.ptr(ztE), L.ptr(nm),
+            *[L.ptr(t) for t in tabs], C.c_float(temperature[0]), C.c_float(temperature[1]),
+            L.ptr(n_(qX)), L.ptr(e_(qE)), L.ptr(oX), L.ptr(oE), L.ptr(n_(mx)), L.ptr(e_(me)),
+            L.ptr(n_(probX)), L.ptr(e_(probE)), L.ptr(n_(zsX)), L.ptr(e_(zsE)),
+            C.c_int(B), C.c_int(n), C.c_int(kx), C.c_int(ke), L.stream()), 'da_posterior_sample')
+
+    from . import engine
+    sides = engine._side_stream(dev)
+    if sides is None:
+        launch(True, True)
+    else:
+        # the node half (few workgroups, latency-bound) beside the edge half; every tensor was allocated on the main stream
+        # and the main stream joins before anything is returned
+        main = torch.cuda.current_stream()
+        ready = main.record_event()
+        with torch.cuda.stream(sides[1]):
+            sides[1].wait_event(ready)
+            launch(True, False)
+            done = sides[1].record_event()
+        launch(False, True)
+        main.wait_event(done)
     return probX, probE, zsX, zsE
 
 
