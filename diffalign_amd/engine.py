@@ -240,8 +240,9 @@ def _side_stream(dev):
     of a layer's input stay on the main stream (one HBM-bound pass; the edge kernel owns every CU's registers, nothing
     overlaps with it; on a third stream, beside the node tail and the next q/k/v, it made the step 1-2 % slower).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
     the edge kernel of layer l so that they run beside the node tail of layer l and the q/k/v and statistics passes of
-    layer l+1; the main stream joins right before the edge kernel of layer l+1.  The Xtoy statistics (13 us) get a stream
-    of their own beside q/k/v.  Returns (y stream, statistics stream) or None."""
+    layer l+1; the main stream joins right before the edge kernel of layer l+1.  A second side stream carries what depends on the
+    node features only: the Xtoy statistics beside q/k/v, the node input / output paths beside the edge input / output
+    stages, and (helpers.posterior_sample) the node half of the reverse step.  Returns (y stream, node stream) or None."""
     if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
