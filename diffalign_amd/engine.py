@@ -299,8 +299,21 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
                                _i(pm.he), S), 'da_edge_in_sym')
     yh = torch.empty(B, pm.dy, device=dev)
-    L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
-                        _i(pm.dy_in), _i(pm.hy), _i(pm.dy), S), 'da_y_in')
+    film0 = film_buffers(pm, B, dev) if side is not None else None
+    y_done0 = None
+
+    def y_input_path():
+        L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
+                            _i(pm.dy_in), _i(pm.hy), _i(pm.dy), L.stream()), 'da_y_in')
+
+    if side is None:
+        y_input_path()
+    else:                                            # y input MLP and the first layer's FiLM vectors beside the edge input stage
+        with torch.cuda.stream(side):
+            side.wait_event(in_ready)
+            y_input_path()
+            layer_film(pm, pm.layers[0], yh, B, film0)
+            y_done0 = side.record_event()
     if xin_done is not None:
         main.wait_event(xin_done)
     # ---- layers
@@ -310,8 +323,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
         # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
-        film = layer_film(pm, pm.layers[0], yh, B, film_buffers(pm, B, dev))
-        y_done = None
+        film, y_done = film0, y_done0
         keep = []
         for li, lw in enumerate(pm.layers):
             tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
