@@ -796,7 +796,6 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
                   newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, stats, stats_nchunk, ticket};
-  if (stats && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { da_set_error("da_edge_layer_stats: memset failed"); return DA_ERR_HIP; }
   { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
     const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2);
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
@@ -839,7 +838,8 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
 
 // da_edge_layer that also leaves the Etoy statistics partials of E_in (da_edge_stats' layout, stats_nchunk chunks per graph)
 // in stats_partials: the waves that finish their share of the layer early compute them (see the kernel's tail).
-// ticket: 4 bytes of device scratch.
+// ticket: one int of device memory that is ZERO when the kernel starts (the caller clears it, ahead of whatever the launch
+// waits for, so that no memset sits between the layer's dependencies and the kernel); the kernel leaves it non-zero.
 int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,

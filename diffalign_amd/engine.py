@@ -164,6 +164,7 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
     nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(R, dx, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev) if stats_out is not None else None   # cleared ahead of the join below
     if before_edge is not None:
         before_edge()
     if PROFILE_EVENTS is not None:
@@ -173,7 +174,6 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
             C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
             L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
     if stats_out is not None:
-        ticket = torch.empty(1, dtype=torch.int32, device=dev)
         L.check(lib.da_edge_layer_stats(*args, L.ptr(stats_out), _i(stats_out.shape[1]), L.ptr(ticket), S), 'da_edge_layer_stats')
     else:
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')

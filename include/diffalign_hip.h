@@ -191,8 +191,9 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
                   long long split_scratch_bytes, void* stream);
 /* da_edge_layer that also produces the Etoy statistics of its INPUT tensor (what the y branch of the same layer needs,
  * layers.py:31-47) in da_edge_stats' partials layout [B][stats_nchunk][4][de]: the waves that finish their share of the
- * layer early stream E_in once more instead of idling, so the separate statistics pass disappears.  ticket: 4 bytes of
- * device scratch.  Same E_out / newX_in as da_edge_layer, bit for bit. */
+ * layer early stream E_in once more instead of idling, so the separate statistics pass disappears.  ticket: one int
+ * of device memory that is zero when the kernel starts (cleared by the caller; the kernel leaves it non-zero).  Same E_out /
+ * newX_in as da_edge_layer, bit for bit. */
 int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
