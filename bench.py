@@ -108,9 +108,23 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, BEFORE anything touches the GPU in this
+        # process (the ranks are children; this process only waits and hands on their exit code and rank 0's JSON line)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     torch.cuda.set_device(local)
@@ -179,6 +193,11 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        if dist is not None:
+            # the one collective of sharded sampling (diffalign_amd/distributed.py): the final gather of the collapsed uint8
+            # results, n + n*n bytes per chain, inside the timed region
+            from diffalign_amd.distributed import gather_collapsed
+            gather_collapsed(z_t.X.argmax(-1).to(torch.uint8), z_t.E.argmax(-1).to(torch.uint8))
         sync()
         dt = time.perf_counter() - t0
     ev = engine.PROFILE_EVENTS

@@ -17,6 +17,67 @@ _lib: Optional[C.CDLL] = None
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
+# Signatures of include/diffalign_hip.h, 'return:arguments' with p = pointer (void*), i = int, q = long long, f = float,
+# s = const char*; set on the library once, so that no call site can truncate a size or pass a float as a double
+# (tests/test_abi_exports.py checks this table against the header).
+SIGNATURES = {
+    'da_abi_version': 'i:',
+    'da_last_error': 's:',
+    'da_mask_dense': 'i:pppiiiip',
+    'da_collapse': 'i:pppppiiiip',
+    'da_free_masks': 'i:pppiiiiiipippp',
+    'da_apply_mask': 'i:ppppppiiiiip',
+    'da_posterior_sample': 'i:pppppppppppffppppppppppiiiip',
+    'da_sample_discrete': 'i:pppppppppiiiip',
+    'da_noise_probs': 'i:pppppppiiiip',
+    'da_elbo_rows': 'i:ippppppppppippppfppiiiip',
+    'da_masked_sums': 'i:pppppiip',
+    'da_ce_grad': 'i:pppppppffppiiiip',
+    'da_skip_grad': 'i:pppipippiiiip',
+    'da_edge_blob_bytes': 'q:iii',
+    'da_edge_in_blob_bytes': 'q:ii',
+    'da_edge_out_blob_bytes': 'q:ii',
+    'da_kv_frag_bytes': 'q:iii',
+    'da_x_post_blob_bytes': 'q:ii',
+    'da_linear': 'i:pipipppiiiiip',
+    'da_x_post': 'i:pppppiiip',
+    'da_add_layernorm': 'i:pppppiip',
+    'da_x_in_finish': 'i:pppiip',
+    'da_edge_in': 'i:pipppiiiip',
+    'da_edge_in_scratch_bytes': 'q:iii',
+    'da_edge_in_sym': 'i:pippppiiiip',
+    'da_edge_stats_table': 'i:ppiiiip',
+    'da_edge_stats_skip': 'i:pppiiiip',
+    'da_y_in': 'i:ppppppiiiip',
+    'da_y_film': 'i:ppppppiiiip',
+    'da_qkv_frag': 'i:ppppppiiip',
+    'da_kv_pack': 'i:ppipiiip',
+    'da_edge_layer': 'i:pppippppppppfiiiiipqp',
+    'da_edge_layer_stats': 'i:pppippppppppfiiiiipqpipp',
+    'da_edge_layer_tuning': 'i:iiiii',
+    'da_edge_split_scratch_bytes': 'q:iii',
+    'da_edge_stats': 'i:ppiiiip',
+    'da_x_stats': 'i:ppiiiip',
+    'da_y_update': 'i:pppppiiiiiiiip',
+    'da_align_index': 'i:pppiip',
+    'da_x_out_finish': 'i:pipipppiiip',
+    'da_edge_out': 'i:ppipppppiiiiip',
+    'da_edge_out_tiles': 'i:ppipppppiiiiip',
+    'da_edge_out_g': 'i:pppiiiip',
+    'da_edge_out_finish': 'i:ppippppiiip',
+    'da_extra_adjacency': 'i:pppppppiiip',
+    'da_extra_cycles': 'i:ppppppiip',
+    'da_extra_eigen': 'i:ppqqppppppiip',
+    'da_extra_eigen_solve': 'i:ppppppppiip',
+    'da_extra_molecular': 'i:pppppfppiiip',
+    'da_pos_product_index': 'i:pppppiip',
+    'da_pos_sinusoidal': 'i:pppqip',
+    'da_pos_gather_rows': 'i:pppiiiip',
+    'da_pos_laplacian': 'i:pppiip',
+    'da_pos_lap_gather': 'i:pqqpppppiiiip',
+}
+_CT = {'p': C.c_void_p, 'i': C.c_int, 'q': C.c_longlong, 'f': C.c_float, 's': C.c_char_p}
+
 
 class DiffAlignHipError(RuntimeError):
     pass
@@ -29,7 +90,14 @@ def lib() -> C.CDLL:
             raise DiffAlignHipError(f'{LIB_PATH} is missing: build it with `python -m diffalign_amd.build` '
                                     '(hipcc, gfx950). There is no CPU fallback.')
         _lib = C.CDLL(LIB_PATH)
-        _lib.da_last_error.restype = C.c_char_p
+        for name, sig in SIGNATURES.items():
+            ret, args = sig.split(':')
+            try:
+                fn = getattr(_lib, name)
+            except AttributeError:
+                raise DiffAlignHipError(f'{LIB_PATH} does not export {name}: rebuild it (python -m diffalign_amd.build)') from None
+            fn.restype = _CT[ret]
+            fn.argtypes = [_CT[a] for a in args]
     return _lib
 
 

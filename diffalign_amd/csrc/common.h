@@ -7,6 +7,7 @@
 #define DA_ERR_ARG -1
 #define DA_ERR_HIP -2
 #define DA_ERR_UNSUPPORTED -3
+#define DA_MAX_DEVICES 64
 
 void da_set_error(const char* fmt, ...);
 

@@ -13,6 +13,7 @@
 // newE^T (channels in registers, pair on the lane) -> LN1 -> FFN chained through accumulators -> LN2 -> store.
 // No LDS traffic for activations, no barriers in the main loop.
 #include "mfma_util.h"
+#include <atomic>
 #include <cstdlib>
 
 // Timing-experiment hooks (tools/build_variant.sh): each removes one cost to measure what it hides.  Results are WRONG
@@ -610,7 +611,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     const int g = lane % G, rl = lane / G;
     for (;;) {
       int t = 0;
-      if (lane == 0) t = atomicAdd(a.ticket, 1);
+      if (lane == 0) {
+        t = atomicAdd(a.ticket, 1);
+        // every wave of the grid draws exactly one ticket >= ntick: whoever draws the last of them puts the counter back to zero
+        if (t == ntick + (int)gridDim.x * NW - 1) atomicExch(a.ticket, 0);
+      }
       t = __shfl(t, 0);
       if (t >= ntick) break;
       const int b = t / nchunk, ch = t - b * nchunk;
@@ -715,23 +720,33 @@ template <int DE, int DX, int DFF, int NT_>
 static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
   using C = EdgeCfg<DE, DX, DFF>;
   auto kern = k_edge_layer<DE, DX, DFF, NT_>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set[DA_MAX_DEVICES];     // the attribute is per device (and per template instance)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("edge layer: no current HIP device"); return DA_ERR_HIP; }
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
-    attr_set = true;
+    attr_set[dev].store(true, std::memory_order_release);
   }
   kern<<<grid_blocks, NT_, C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4, s>>>(a);
   return DA_OK;
 }
-static int g_edge_threads = 0;
-static int edge_threads() {
-  if (g_edge_threads == 0) {
-    const char* e = getenv("DA_EDGE_THREADS");
-    g_edge_threads = (e && atoi(e) == 256) ? 256 : 512;   // default: 8 waves/workgroup = 2 waves per SIMD
-  }
-  return g_edge_threads;
+// Tuning knobs of the launch (-1 = choose automatically).  Read from the environment once (DA_EDGE_THREADS, DA_EDGE_SKEW,
+// DA_EDGE_TAIL_OLD, DA_EDGE_STAGGER, DA_EDGE_PRIO) and settable through da_edge_layer_tuning (tests, A/B timing).  Process-wide:
+// change them only while no other thread is inside da_edge_layer.
+struct EdgeTuning { int threads, skew, tail_old, stagger, prio; };
+static EdgeTuning& edge_tuning() {
+  static EdgeTuning t = [] {
+    auto env = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
+    EdgeTuning u;
+    u.threads = env("DA_EDGE_THREADS", 512) == 256 ? 256 : 512;   // default: 8 waves/workgroup = 2 waves per SIMD
+    u.skew = env("DA_EDGE_SKEW", -1); u.tail_old = env("DA_EDGE_TAIL_OLD", -1);
+    u.stagger = env("DA_EDGE_STAGGER", 0); u.prio = env("DA_EDGE_PRIO", 0);
+    return u;
+  }();
+  return t;
 }
+static int edge_threads() { return edge_tuning().threads; }
 template <int DE, int DX, int DFF>
 static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
   if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
@@ -752,6 +767,17 @@ static int edge_max_rem(int rows, int n) {
 }
 
 extern "C" {
+
+// Launch tuning of da_edge_layer (see EdgeTuning): threads 256 | 512 (0 = keep), skew / tail_old -1 = automatic, stagger, prio.
+// da_edge_split_scratch_bytes depends on `threads`: size the scratch after this call.
+int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio) {
+  DA_CHECK_ARG(threads == 0 || threads == 256 || threads == 512, "da_edge_layer_tuning: threads must be 0 (keep), 256 or 512");
+  DA_CHECK_ARG(skew >= -1 && tail_old >= -1 && tail_old <= 1 && stagger >= 0 && prio >= 0 && prio <= 3, "da_edge_layer_tuning: bad value");
+  EdgeTuning& t = edge_tuning();
+  if (threads) t.threads = threads;
+  t.skew = skew; t.tail_old = tail_old; t.stagger = stagger; t.prio = prio;
+  return DA_OK;
+}
 
 // size in bytes of the packed per-layer weight blob the edge kernel expects (layout: EdgeCfg / diffalign_amd/pack.py)
 long long da_edge_blob_bytes(int de, int dx, int dff) {
@@ -796,8 +822,8 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
                   newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, stats, stats_nchunk, ticket};
-  { const char* e1 = getenv("DA_EDGE_STAGGER"); if (e1) a.stagger = atoi(e1);
-    const char* e2 = getenv("DA_EDGE_PRIO"); if (e2) a.prio = atoi(e2);
+  { const EdgeTuning tune = edge_tuning();
+    a.stagger = tune.stagger; a.prio = tune.prio;
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
     // default shares: ~57 % of a SIMD pair's tiles to the older wave (the per-slot run times of the EXP_STAMP build cross there:
     // older 2067 + 209 s, younger 2595 - 162 s k-cycles for s rows of skew at 9 rows per wave), from whole rows of skew plus,
@@ -812,8 +838,8 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
           if (d < best) { best = d; a.skew = sk; a.tail_old = to; }
         }
     }
-    const char* e3 = getenv("DA_EDGE_SKEW"); if (e3) a.skew = atoi(e3);
-    const char* e4 = getenv("DA_EDGE_TAIL_OLD"); if (e4) a.tail_old = atoi(e4); }
+    if (tune.skew >= 0) a.skew = tune.skew;
+    if (tune.tail_old >= 0) a.tail_old = tune.tail_old; }
   int rc;
   if (de == 64 && dx == 256 && dff == 128) rc = launch_edge<64, 256, 128>(a, grid, (hipStream_t)stream);
   else if (de == 32 && dx == 64 && dff == 64) rc = launch_edge<32, 64, 64>(a, grid, (hipStream_t)stream);
@@ -838,8 +864,8 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
 
 // da_edge_layer that also leaves the Etoy statistics partials of E_in (da_edge_stats' layout, stats_nchunk chunks per graph)
 // in stats_partials: the waves that finish their share of the layer early compute them (see the kernel's tail).
-// ticket: one int of device memory that is ZERO when the kernel starts (the caller clears it, ahead of whatever the launch
-// waits for, so that no memset sits between the layer's dependencies and the kernel); the kernel leaves it non-zero.
+// ticket: one int of device memory that is ZERO when the kernel starts; the kernel's last wave puts it back to zero, so a
+// caller clears it once, when it allocates it, and may hand the same word to every later launch on the same stream.
 int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,

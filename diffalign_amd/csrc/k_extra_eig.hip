@@ -12,6 +12,7 @@
 // Inside a degenerate eigenspace (the zero eigenvalues of a graph with several components; symmetric molecules) the
 // vectors are one basis among many, as the reference's LAPACK vectors are: eigenvalue features are comparable, the
 // eigenvector features only through basis-independent properties (tests/golden/common.py:check_extra).
+#include <atomic>
 #include "common.h"
 
 #define EIG_THREADS 1024
@@ -415,11 +416,13 @@ int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_n
   DA_CHECK_ARG(B >= 0 && n >= 1 && n <= 1024, "da_extra_eigen_solve: n = %d outside 1..1024 (LDS work arrays)", n);
   if (B == 0) return DA_OK;
   const size_t lds = ((size_t)17 * n + 32 + 8) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set[DA_MAX_DEVICES];     // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_extra_eigen_solve: no current HIP device"); return DA_ERR_HIP; }
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_extra_eig_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) { da_set_error("da_extra_eigen_solve: cannot reserve LDS: %s", hipGetErrorString(e)); return DA_ERR_HIP; }
-    attr_set = true;
+    attr_set[dev].store(true, std::memory_order_release);
   }
   DA_CHECK_ARG(lds <= 160 * 1024 - 64, "da_extra_eigen_solve: n = %d needs %zu B of LDS", n, lds);
   k_extra_eig_solve<<<B, EIG_THREADS, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n);

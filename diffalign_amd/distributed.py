@@ -25,21 +25,41 @@ def chain_seed(seed: int, global_index: int) -> int:
     return (seed * 0x9E3779B1 + global_index * 0x85EBCA77) & 0x7FFFFFFF
 
 
+def collective_device(group=None) -> torch.device:
+    """Device the group's collectives run on: the current HIP device under 'nccl' (= RCCL), the host under 'gloo'."""
+    if dist.is_initialized() and 'nccl' in str(dist.get_backend(group)):
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def gather_collapsed(X: torch.Tensor, E: torch.Tensor, group=None):
+    """The final gather of sharded sampling for equal shards: every rank's collapsed uint8 results (m, n) / (m, n, n) ->
+    lists of `world` tensors on every rank (one all_gather each; weak-scaling bench)."""
+    world = dist.get_world_size(group)
+    Xs = [torch.empty_like(X) for _ in range(world)]
+    Es = [torch.empty_like(E) for _ in range(world)]
+    dist.all_gather(Xs, X.contiguous(), group=group)
+    dist.all_gather(Es, E.contiguous(), group=group)
+    return Xs, Es
+
+
 def sample_sharded(n_conditions: int, n_samples: int, n_nodes: int,
                    sample_fn: Callable[[List[Tuple[int, int]]], Tuple[torch.Tensor, torch.Tensor]],
-                   group=None, dst: int = 0) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+                   group=None, dst: int = 0, device=None) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """sample_fn(units) -> (X_idx uint8 (len(units), n), E_idx uint8 (len(units), n, n)) for units = [(cond, sample)].
-    Returns on rank `dst` the results for all n_conditions*n_samples chains in (condition-major) order, else None."""
+    Returns on rank `dst` the results for all n_conditions*n_samples chains in (condition-major) order, else None.
+    `device`: where the gathered tensors live (default: the group's collective device); a rank whose shard is empty
+    (fewer chains than ranks) contributes empty tensors on that same device."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     total = n_conditions * n_samples
     s, e = shard_range(total, rank, world)
     units = [(g // n_samples, g % n_samples) for g in range(s, e)]
+    dev = torch.device(device) if device is not None else collective_device(group)
     if units:
         X, E = sample_fn(units)
-        X, E = X.to(torch.uint8).contiguous(), E.to(torch.uint8).contiguous()
+        X, E = X.to(device=dev, dtype=torch.uint8).contiguous(), E.to(device=dev, dtype=torch.uint8).contiguous()
     else:
-        dev = 'cpu'
         X = torch.empty(0, n_nodes, dtype=torch.uint8, device=dev); E = torch.empty(0, n_nodes, n_nodes, dtype=torch.uint8, device=dev)
     if world == 1:
         return X, E

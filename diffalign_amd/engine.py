@@ -56,7 +56,6 @@ class PackedModel:
         self.de_in = g('mlp_in_E.0.weight').shape[1]
         self.dy_in = g('mlp_in_y.0.weight').shape[1]
         lib = L.lib()
-        lib.da_edge_blob_bytes.restype = C.c_longlong
         if lib.da_edge_blob_bytes(_i(self.de), _i(self.dx), _i(self.dffe)) < 0:
             raise L.DiffAlignHipError(f'hidden dims (de={self.de}, dx={self.dx}, dim_ffE={self.dffe}) are not built into '
                                       'libdiffalign_hip.so; built: (64,256,128) and (32,64,64)')
@@ -68,9 +67,9 @@ class PackedModel:
         self.skip = None
         if prefix + 'skip_scaling' in sd:
             self.skip = (f32(g('skip_scaling')), f32(g('skip_scaling_2')))
-        lib.da_x_post_blob_bytes.restype = C.c_longlong
         self.fused_x = lib.da_x_post_blob_bytes(_i(self.dx), _i(self.dffx)) > 0     # else: the unfused da_linear chain
         self.fused_qkv = self.dx in (256, 64)                                       # else: da_linear + da_kv_pack
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # da_edge_layer_stats' work counter: the kernel leaves it zero
         self.layers = []
         for l in range(n_layers):
             p = f'tf_layers.{l}'
@@ -147,7 +146,6 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
     lib = L.lib()
     S = L.stream()
     ye2p1, ebias, yx1, yx2p1 = film if film is not None else layer_film(pm, lw, y, B, film_buffers(pm, B, dev))
-    lib.da_kv_frag_bytes.restype = C.c_longlong
     kvf = torch.empty(lib.da_kv_frag_bytes(_i(B), _i(n), _i(dx)), dtype=torch.uint8, device=dev)
     if pm.fused_qkv:
         Qm = torch.empty(R, dx, device=dev); ldq = dx
@@ -160,11 +158,10 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
         L.check(lib.da_kv_pack(C.c_void_p(Qm.data_ptr() + dx * fsz), C.c_void_p(Qm.data_ptr() + 2 * dx * fsz), _i(3 * dx),
                                L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
     E_out = torch.empty_like(E_bf16)
-    lib.da_edge_split_scratch_bytes.restype = C.c_longlong
     nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(R, dx, device=dev)
-    ticket = torch.zeros(1, dtype=torch.int32, device=dev) if stats_out is not None else None   # cleared ahead of the join below
+    ticket = pm.ticket if stats_out is not None else None
     if before_edge is not None:
         before_edge()
     if PROFILE_EVENTS is not None:
@@ -294,7 +291,6 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             node_input_path()
             xin_done = side2.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
-    lib.da_edge_in_scratch_bytes.restype = C.c_longlong
     sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
                                _i(pm.he), S), 'da_edge_in_sym')

@@ -192,12 +192,19 @@ int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const 
 /* da_edge_layer that also produces the Etoy statistics of its INPUT tensor (what the y branch of the same layer needs,
  * layers.py:31-47) in da_edge_stats' partials layout [B][stats_nchunk][4][de]: the waves that finish their share of the
  * layer early stream E_in once more instead of idling, so the separate statistics pass disappears.  ticket: one int
- * of device memory that is zero when the kernel starts (cleared by the caller; the kernel leaves it non-zero).  Same E_out /
+ * of device memory that is zero when the kernel starts; the kernel's last wave puts it back to zero, so the caller clears it once.  Same E_out /
  * newX_in as da_edge_layer, bit for bit. */
 int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                         long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, void* stream);
+/* Launch tuning of da_edge_layer / da_edge_layer_stats, process-wide (no counterpart in the reference; for tests and A/B timing):
+ * threads per workgroup 256 | 512 (0 = keep), skew = whole rows the older wave of every SIMD pair takes more than the younger one,
+ * tail_old = the split rows' runs go to the older waves only (both: -1 = chosen from the problem size), stagger, prio = start
+ * delay / s_setprio level of the younger half.  Results do not depend on any of them beyond the fp32 order of the softmax merge of
+ * split rows.  da_edge_split_scratch_bytes depends on `threads`.  Defaults come from DA_EDGE_THREADS / _SKEW / _TAIL_OLD /
+ * _STAGGER / _PRIO, read once. */
+int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio);
 /* Load balance of da_edge_layer's persistent grid: with a scratch of this many bytes (0: not needed for this size) the
  * query rows of the last, incomplete round are cut into runs of key tiles over all waves and folded by a small second
  * kernel; without it (NULL) whole rows only.  Results are identical up to the fp32 order of the softmax merge. */

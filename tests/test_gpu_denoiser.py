@@ -70,7 +70,6 @@ def test_edge_in_table_path_shapes(n):
     nm = torch.rand(B, n, generator=g) < 0.8
     E[3] = E[3] * (nm[3, :, None, None] & nm[3, None, :, None])            # graph 3: masked pairs all zero
     E_d, nm_d = E.to(D), L.as_u8(nm.to(D))
-    L.lib().da_edge_in_scratch_bytes.restype = engine.C.c_longlong
     scratch = torch.empty(int(L.lib().da_edge_in_scratch_bytes(engine._i(B), engine._i(KE), engine._i(hd['de']))), dtype=torch.uint8, device=D)
     a_ = torch.empty(B, n, n, hd['de'], dtype=torch.bfloat16, device=D); b_ = torch.full_like(a_, 7.0)
     args = (engine._i(B), engine._i(n), engine._i(hd['de']), engine._i(FULL['hidden_mlp_dims']['E']), L.stream())
@@ -119,7 +118,6 @@ def test_stages_vs_oracle(dims):
     Esym = ((Ea + Ea.transpose(1, 2)) / 2); Esym[2] = E[2]                  # symmetric, graphs 0 and 1 not one-hot
     Ehot = E.clone(); Ehot[0, 2, 7] = Ehot[0, 2, 7].roll(1)                   # graph 0 one-hot but not symmetric
     assert not torch.equal(Ehot, E)
-    L.lib().da_edge_in_scratch_bytes.restype = engine.C.c_longlong
     flags = torch.empty(int(L.lib().da_edge_in_scratch_bytes(engine._i(B), engine._i(KE), engine._i(hd['de']))), dtype=torch.uint8, device=D)
     seen = []
     for src_ in (E_d, Ea_d, Emix.to(D), Esym.to(D), Ehot.to(D)):
