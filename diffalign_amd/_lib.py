@@ -46,6 +46,7 @@ SIGNATURES = {
     'da_edge_in': 'i:pipppiiiip',
     'da_edge_in_scratch_bytes': 'q:iii',
     'da_edge_in_sym': 'i:pippppiiiip',
+    'da_edge_in_sym_static': 'i:pipppiiiip',
     'da_edge_stats_table': 'i:ppiiiip',
     'da_edge_stats_skip': 'i:pppiiiip',
     'da_y_in': 'i:ppppppiiiip',

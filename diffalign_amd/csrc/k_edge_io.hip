@@ -568,6 +568,10 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
 #ifndef EXP_IOGRID_CAP
 #define EXP_IOGRID_CAP 2048
 #endif
+// Scratch of da_edge_in_sym_static: flags, table and class counts for up to DA_EDGE_IN_STATIC_MAX_B graphs (da_edge_in_scratch_bytes
+// (4096, 16, 64) = 273,152 B).  Host code never uses this name as an address: hipGetSymbolAddress, per device.
+#define DA_EDGE_IN_STATIC_MAX_B 4096
+static __device__ __align__(256) uint8_t g_edge_in_scratch[288 * 1024];
 static inline size_t in_table_offset(int B) { return ((size_t)2 * B + 255) / 256 * 256; }
 static inline size_t in_hist_offset(int B, int de_in, int de) { return (in_table_offset(B) + (size_t)(de_in + 2) * de * 2 + 255) / 256 * 256; }
 static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
@@ -660,6 +664,28 @@ int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const
   if (rc) return rc;
   DA_CHECK_LAUNCH("da_edge_in_sym");
   return DA_OK;
+}
+
+// da_edge_in_sym for callers that cannot allocate (HIP graph capture, serving loops): the scratch is a static device array of the
+// library instead of a workspace argument.  No hipMalloc / hipFree; B <= DA_EDGE_IN_STATIC_MAX_B.  The array belongs to the
+// device: calls on one GPU share it, so calls that overlap on one GPU (different streams) race; it is rewritten by every call.
+int da_edge_in_sym_static(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
+                          int he, void* stream) {
+  DA_CHECK_ARG(B >= 0 && B <= DA_EDGE_IN_STATIC_MAX_B, "da_edge_in_sym_static: B = %d exceeds the static scratch (B <= %d); use da_edge_in_sym "
+               "with a caller-owned scratch", B, DA_EDGE_IN_STATIC_MAX_B);
+  DA_CHECK_ARG(de_in >= 1 && de_in <= 16 && de >= 8 && de <= 64, "da_edge_in_sym_static: widths (de_in=%d, de=%d) outside the static scratch's layout", de_in, de);
+  if (B == 0 || n == 0) return DA_OK;
+  DA_CHECK_ARG((size_t)da_edge_in_scratch_bytes(B, de_in, de) <= sizeof(g_edge_in_scratch), "da_edge_in_sym_static: scratch too small");
+  static uint8_t* ptr_of_device[DA_MAX_DEVICES];      // device address of g_edge_in_scratch, per GPU (each holds its own copy)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_edge_in_sym_static: no current HIP device"); return DA_ERR_HIP; }
+  uint8_t* scratch = __atomic_load_n(&ptr_of_device[dev], __ATOMIC_ACQUIRE);
+  if (scratch == nullptr) {
+    hipError_t e = hipGetSymbolAddress((void**)&scratch, HIP_SYMBOL(g_edge_in_scratch));
+    if (e != hipSuccess || scratch == nullptr) { da_set_error("da_edge_in_sym_static: hipGetSymbolAddress: %s", hipGetErrorString(e)); return DA_ERR_HIP; }
+    __atomic_store_n(&ptr_of_device[dev], scratch, __ATOMIC_RELEASE);
+  }
+  return da_edge_in_sym(E_in, de_in, node_mask, blob, E_h, scratch, B, n, de, he, stream);
 }
 
 // E logits = sym((mlp_out_E(E_h)+E_in[..., :ke])*offdiag) [+ skip]   transformer_model_with_y.py:672-704

@@ -155,6 +155,12 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
 long long da_edge_in_scratch_bytes(int B, int de_in, int de);
 int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* sym_flags, int B,
                    int n, int de, int he, void* stream);
+/* da_edge_in_sym without a workspace argument, for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The scratch is a 288 KiB static
+ * __device__ array of the library, per GPU; B <= 4096 (larger batches: DA_ERR_ARG; use da_edge_in_sym).  Allocates nothing.
+ * Calls on one GPU share the array: calls that overlap on one GPU race.  Same E_h as da_edge_in_sym, bit for bit. */
+int da_edge_in_sym_static(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, int B, int n, int de,
+                          int he, void* stream);
 /* Etoy statistics of the stage's output without another pass over it: da_edge_stats_table writes da_edge_stats' partials
  * for the graphs da_edge_in_sym served from its table (from the class counts it left in `scratch`), da_edge_stats_skip
  * runs da_edge_stats on the other graphs only (skip = the same scratch).  Sums are exact products count x value instead of
