@@ -27,6 +27,9 @@ SIGNATURES = {
     'da_collapse': 'i:pppppiiiip',
     'da_free_masks': 'i:pppiiiiiipippp',
     'da_apply_mask': 'i:ppppppiiiiip',
+    'da_to_dense': 'i:ppppppqqiiiippppppp',
+    'da_inpaint': 'i:pipippppppiiiip',
+    'da_counter_exp_noise': 'i:pqppiiiip',
     'da_posterior_sample': 'i:pppppppppppffppppppppppiiiip',
     'da_sample_discrete': 'i:pppppppppiiiip',
     'da_noise_probs': 'i:pppppppiiiip',

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   double* s_w = sm + 8 * n;         // 9n  work of the three tridiagonal solves (a, b, c each)
   double* s_red = sm + 17 * n;      // 32
   double* s_lam = s_red + 32;       // 8
+  double* s_pp = s_lam + 8;         // EIG_THREADS  partial sums of A u per (row class, column): summed in a fixed order
   __shared__ int s_ncomp, s_nreal, s_best;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NWV = EIG_THREADS / 64;
@@ -143,8 +144,9 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
 #endif
   // ---- 1. tridiagonalisation (rows k = n-1 .. 1; reflector u_k stored in A[k][0:k], h_k = u^T u / 2 in s_h).
   // Five barriers per step: the step is latency bound (one workgroup per matrix), so phases are merged wherever the data
-  // allows: reductions through per-wave partials that every thread sums itself, p accumulated with LDS atomics, q never
-  // materialised.
+  // allows: reductions through per-wave partials that every thread sums itself, p from per-row-class partials in LDS that the
+  // column's own thread adds up in a fixed order (bit-reproducible: the sampled chains downstream flip draws on 1-ulp changes of
+  // the eigen-features), q never materialised.
   double* s_part = s_red;          // [2][16] per-wave partials, double buffered
   int* s_iu = reinterpret_cast<int*>(s_w);             // [n] compacted index list
   int* s_wc = reinterpret_cast<int*>(s_w + n);         // [16] per-wave counts of the compaction
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
     // rows of the product A u, T = {j: u_j != 0 or (A u)_j != 0} the rank-2 update.  Ordered compaction (deterministic sums).
     const int nU = compact(s_iu, s_wc, k, [&](int j) { return s_u[j] != 0.0; });
     // h p = A u.  A is symmetric: (A u)_j = sum_{i in U} A[i][j] u_i, one thread per column j and row class, the rows walked
-    // with 16 independent loads in flight; coalesced in j; partial sums meet in LDS atomics
+    // with 16 independent loads in flight; coalesced in j; partial sums meet in s_pp[row class][column]
     const int CW = (k + 63) & ~63;                      // columns rounded up to whole waves
     const int RC = EIG_THREADS / CW > 0 ? EIG_THREADS / CW : 1;
     for (int t = tid; t < RC * CW; t += EIG_THREADS) {
@@ -191,11 +193,16 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
       }
       for (; ii < nU; ii += RC) { const int i = s_iu[ii]; acc[0] = fma(A[(size_t)i * n + j], s_u[i], acc[0]); }
       const double tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      if (tot != 0.0) atomicAdd(&s_p[j], tot);
+      s_pp[rc * CW + j] = tot;
     }
     __syncthreads();                                                              // (4)
     double kp = 0.0;
-    for (int j = tid; j < k; j += EIG_THREADS) kp = fma(s_u[j], s_p[j], kp);
+    for (int j = tid; j < k; j += EIG_THREADS) {        // k <= EIG_THREADS: thread j owns column j here and in compact() below
+      double pj = 0.0;
+      for (int rc = 0; rc < RC; ++rc) pj += s_pp[rc * CW + j];
+      s_p[j] = pj;
+      kp = fma(s_u[j], pj, kp);
+    }
     kp = wsum(kp);
     if (lane == 0) s_part[16 + wave] = kp;
     const int nT = compact(s_iu, s_wc, k, [&](int j) { return s_u[j] != 0.0 || s_p[j] != 0.0; });   // (barriers inside)
@@ -415,7 +422,7 @@ int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_n
                          float* vec2, double* evals6 /*may be NULL*/, int B, int n, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 1 && n <= 1024, "da_extra_eigen_solve: n = %d outside 1..1024 (LDS work arrays)", n);
   if (B == 0) return DA_OK;
-  const size_t lds = ((size_t)17 * n + 32 + 8) * sizeof(double);
+  const size_t lds = ((size_t)17 * n + 32 + 8 + EIG_THREADS) * sizeof(double);
   static std::atomic<bool> attr_set[DA_MAX_DEVICES];     // the attribute is per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_extra_eigen_solve: no current HIP device"); return DA_ERR_HIP; }

@@ -1,4 +1,5 @@
-"""ELBO ranking driver: the part of `DiscreteDenoisingDiffusionRxn` (diffusion/diffusion_rxn.py) that scores
+"""Sampling drivers (`sample_for_condition`, `sample_n_conditions`: diffusion/diffusion_rxn.py:31-128, BASELINE configs[2]) and the
+ELBO ranking driver: the part of `DiscreteDenoisingDiffusionRxn` (diffusion/diffusion_rxn.py) that scores
 generated samples with the variational bound and ranks them.  The bound itself runs through the HIP kernels
 (`ELBOMixin.elbo`: denoiser, k_elbo_rows, k_masked_sums); ranking is host logic over per-sample scalars and SMILES strings,
 as in the reference.  SMILES conversion (rdkit) stays outside this package: `sort_by_elbo` takes the strings as inputs."""
@@ -9,7 +10,9 @@ import copy
 import numpy as np
 import torch
 
+from . import graph
 from .diffusion_abstract import DiscreteDenoisingDiffusion
+from .placeholder import PlaceHolder
 
 
 def reactions_sorted_with_weighted_prob(restructured_data, lambda_value):
@@ -25,9 +28,82 @@ def reactions_sorted_with_weighted_prob(restructured_data, lambda_value):
     return restructured_data
 
 
+def _to_device(batch, dev):
+    """A PyG-style sparse batch (mapping or attribute object) with its tensors on `dev`."""
+    items = batch.items() if isinstance(batch, dict) else vars(batch).items()
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in items}
+
+
 class DiscreteDenoisingDiffusionRxn(DiscreteDenoisingDiffusion):
     """diffusion/diffusion_rxn.py: scoring and ranking of samples (the chemistry-side methods -- SMILES, plots, dataset
     evaluation -- are out of scope)."""
+
+    @torch.no_grad()
+    def sample_for_condition(self, dense_data, n_samples, inpaint_node_idx, inpaint_edge_idx, device=None, noise_fn=None,
+                             chain_seeds=None):
+        """diffusion_rxn.py:107-128: n_samples chains per condition of `dense_data` (duplicated IN PLACE, as the reference's
+        graph.duplicate_data does: sample_n_conditions relies on it), inpainting lists repeated per sample; returns the final
+        samples collapsed to class indices (X (bs*n_samples, n), E (bs*n_samples, n, n)), which is what
+        sample_one_batch(get_true_rxns=True, get_chains=True) hands back.  noise_fn / chain_seeds: see sample_one_batch."""
+        dup = graph.duplicate_data(dense_data=dense_data, n_samples=n_samples, get_discrete_data=False)
+        rep = lambda idx: [item for item in idx for _ in range(n_samples)] if idx is not None else None
+        final_samples = self.sample_one_batch(data=dup, inpaint_node_idx=rep(inpaint_node_idx), inpaint_edge_idx=rep(inpaint_edge_idx),
+                                              get_true_rxns=True, get_chains=True, device=device, noise_fn=noise_fn,
+                                              chain_seeds=chain_seeds)[0]
+        return final_samples
+
+    @torch.no_grad()
+    def sample_n_conditions(self, dataloader, inpaint_node_idx, inpaint_edge_idx, device_to_use=None, epoch_num=None, seed=0,
+                            group=None, to_smiles=None):
+        """diffusion_rxn.py:31-105 for one process per GPU: the first cfg.test.n_conditions conditions of `dataloader` (an
+        iterable of PyG-style sparse batches -- x, edge_index, edge_attr, batch, y, mask_atom_mapping, mol_assignment -- or of
+        dense PlaceHolders), cfg.test.n_samples_per_condition chains each, (condition, sample) units sharded over the ranks of
+        `group` (distributed.sample_conditions_sharded; the reference walks the conditions in a Python loop, num_gpus per
+        iteration under nn.DataParallel), dense conversion on the device (graph.to_dense).
+        Returns, on rank 0, (all_gen_rxn_smiles, all_true_rxn_smiles, all_gen_rxn_dense, all_true_rxn_dense): per condition the
+        generated / true reactions as collapsed CPU PlaceHolders of n_samples rows (the reference's .pyg() objects hold the
+        same X / E indices) and, when `to_smiles(X, E) -> list[str]` is given (rdkit lives outside this package), their SMILES;
+        (None,) * 4 on the other ranks."""
+        assert epoch_num is not None, f'Need to provide epoch_num to use this function. Got epoch_num={epoch_num}.'
+        from . import distributed
+        dev = torch.device(device_to_use) if device_to_use is not None else self.device_
+        n_cond, n_samples = int(self.cfg.test.n_conditions), int(self.cfg.test.n_samples_per_condition)
+        conditions = []
+        for batch in dataloader:
+            dense = batch if isinstance(batch, PlaceHolder) else graph.to_dense(_to_device(batch, dev))
+            dense = dense.to_device(dev)
+            for k in range(dense.X.shape[0]):
+                nk = int(dense.node_mask[k].sum().item())          # trim to the graph's own size, as a one-graph to_dense gives
+                one = dense.subset_by_idx(k, k + 1)
+                conditions.append(PlaceHolder(X=one.X[:, :nk].contiguous(), E=one.E[:, :nk, :nk].contiguous(), y=one.y,
+                                              node_mask=one.node_mask[:, :nk].contiguous(),
+                                              atom_map_numbers=one.atom_map_numbers[:, :nk].contiguous() if one.atom_map_numbers is not None else None,
+                                              mol_assignments=one.mol_assignments[:, :nk].contiguous() if one.mol_assignments is not None else None))
+                if len(conditions) == n_cond:
+                    break
+            if len(conditions) == n_cond:
+                break
+        assert inpaint_node_idx is None or len(inpaint_node_idx) == len(conditions), 'length of inpaint_node_idx and the number of conditions differ'
+        assert inpaint_edge_idx is None or len(inpaint_edge_idx) == len(conditions), 'length of inpaint_edge_idx and the number of conditions differ'
+        res = distributed.sample_conditions_sharded(conditions, n_samples, self.sample_for_condition, seed=seed,
+                                                    inpaint_node_idx=inpaint_node_idx, inpaint_edge_idx=inpaint_edge_idx, group=group)
+        if res is None:
+            return None, None, None, None
+        X, E = res[0].cpu(), res[1].cpu()
+        gen_dense, true_dense, gen_smiles, true_smiles = [], [], [], []
+        for c, cond in enumerate(conditions):
+            nk = cond.X.shape[1]
+            rows = slice(c * n_samples, (c + 1) * n_samples)
+            gen = PlaceHolder(X=X[rows, :nk].long(), E=E[rows, :nk, :nk].long(), y=torch.zeros(n_samples, 0),
+                              node_mask=cond.node_mask.cpu().expand(n_samples, -1).clone(),
+                              atom_map_numbers=cond.atom_map_numbers.cpu().expand(n_samples, -1).clone() if cond.atom_map_numbers is not None else None,
+                              mol_assignments=cond.mol_assignments.cpu().expand(n_samples, -1).clone() if cond.mol_assignments is not None else None)
+            tc = cond.get_new_object().mask(collapse=True)
+            true = gen.get_new_object(X=tc.X.cpu().expand(n_samples, -1), E=tc.E.cpu().expand(n_samples, -1, -1))
+            gen_dense.append(gen); true_dense.append(true)
+            if to_smiles is not None:
+                gen_smiles.append(to_smiles(gen.X, gen.E)); true_smiles.append(to_smiles(true.X, true.E))
+        return gen_smiles, true_smiles, gen_dense, true_dense
 
     @torch.no_grad()
     def estimate_elbo_with_repeats(self, final_samples_one_hot, noise_fn=None):

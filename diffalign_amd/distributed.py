@@ -80,6 +80,44 @@ def sample_sharded(n_conditions: int, n_samples: int, n_nodes: int,
     return torch.cat(outX, 0), torch.cat(outE, 0)
 
 
+def sample_conditions_sharded(conditions, n_samples: int, sample_for_condition: Callable, seed: int = 0, inpaint_node_idx=None,
+                              inpaint_edge_idx=None, group=None, dst: int = 0, device=None):
+    """BASELINE configs[2]: `n_samples` reverse-diffusion chains for each of len(conditions) conditions, the flattened (condition,
+    sample) index space cut over the ranks (shard_range), no collective inside the chains, one final gather.
+
+    conditions: list of single-graph dense conditions (PlaceHolder-like, X (1,n_c,kx) ...), known to every rank.
+    sample_for_condition(dense_data=, n_samples=k, inpaint_node_idx=, inpaint_edge_idx=, chain_seeds=) -> object with collapsed
+    .X (k,n_c) and .E (k,n_c,n_c): DiscreteDenoisingDiffusionRxn.sample_for_condition (diffusion/diffusion_rxn.py:107-128).
+    A rank calls it once per condition that has chains in its shard, with k = the number of those chains and chain_seeds =
+    chain_seed(seed, global chain index) -- so the samples do not depend on the number of ranks.
+    Returns on rank `dst` (X uint8 (C*n_samples, n_max), E uint8 (C*n_samples, n_max, n_max)) in condition-major order, graphs
+    smaller than n_max = the largest condition zero-padded; None on the other ranks."""
+    n_max = max(int(c.X.shape[1]) for c in conditions) if conditions else 0
+
+    def run(units):
+        outX, outE = [], []
+        k0 = 0
+        while k0 < len(units):
+            c = units[k0][0]
+            k1 = k0
+            while k1 < len(units) and units[k1][0] == c:
+                k1 += 1
+            cond = conditions[c]
+            seeds = torch.tensor([chain_seed(seed, c * n_samples + s_) for _, s_ in units[k0:k1]], dtype=torch.int64)
+            res = sample_for_condition(dense_data=cond.get_new_object(), n_samples=k1 - k0,
+                                       inpaint_node_idx=[inpaint_node_idx[c]] if inpaint_node_idx is not None else None,
+                                       inpaint_edge_idx=[inpaint_edge_idx[c]] if inpaint_edge_idx is not None else None, chain_seeds=seeds)
+            X, E = res.X.to(torch.uint8), res.E.to(torch.uint8)
+            pad = n_max - X.shape[1]
+            if pad:
+                X = torch.nn.functional.pad(X, (0, pad)); E = torch.nn.functional.pad(E, (0, pad, 0, pad))
+            outX.append(X); outE.append(E)
+            k0 = k1
+        return torch.cat(outX, 0), torch.cat(outE, 0)
+
+    return sample_sharded(len(conditions), n_samples, n_max, run, group=group, dst=dst, device=device)
+
+
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
     """Data-parallel training: average the ranks' gradients in place and return them.  The tensors are packed
     in sorted-name order into flat fp32 buckets of <= bucket_bytes (the whole align_absorbing gradient is 32.7 MB: one or

@@ -90,20 +90,70 @@ def apply_mask(orig, z_t, atom_decoder, bond_decoder, mask_nodes=None, mask_edge
     return z
 
 
+def inpaint_lists(node_idx, edge_idx, device):
+    """Python index lists (one list per graph, graph.py:646-654) -> int32 device tensors nodes (Nn,2) rows (b,i), edges (Ne,3)
+    rows (b,i,j); None when there is nothing to fix."""
+    nodes = [(b, int(i)) for b, idx in enumerate(node_idx or []) for i in idx]
+    edges = [(b, int(bond[0]), int(bond[1])) for b, bonds in enumerate(edge_idx or []) for bond in bonds]
+    tn = torch.tensor(nodes, dtype=torch.int32, device=device).reshape(-1, 2) if nodes else None
+    te = torch.tensor(edges, dtype=torch.int32, device=device).reshape(-1, 3) if edges else None
+    return tn, te
+
+
+def _inpaint(nodes, edges, B, n, kx=0, ke=0, mask_X=None, mask_E=None, z=None, orig=None):
+    if nodes is None and edges is None:
+        return
+    zX = zE = oX = oE = None
+    if z is not None:
+        zX, zE, oX, oE = z.X, z.E, orig.X.contiguous().float(), orig.E.contiguous().float()
+        assert zX.is_contiguous() and zE.is_contiguous() and zX.dtype == torch.float32 and zE.dtype == torch.float32
+    L.check(L.lib().da_inpaint(L.ptr(nodes, torch.int32), 0 if nodes is None else nodes.shape[0], L.ptr(edges, torch.int32),
+                               0 if edges is None else edges.shape[0], L.ptr(mask_X), L.ptr(mask_E), L.ptr(zX), L.ptr(zE), L.ptr(oX),
+                               L.ptr(oE), B, n, kx, ke, L.stream()), 'da_inpaint')
+
+
 def fix_nodes_and_edges_by_idx(data, node_idx, edge_idx):
-    """graph.py:621-656: inpainting masks from index lists (all False when None); no deepcopy/collapse."""
+    """graph.py:621-656: inpainting masks (B,n) / (B,n,n) bool from index lists (all False when None), set on the device by one
+    scatter over the lists; no deepcopy / collapse of the batch."""
     B, n = data.X.shape[:2]
-    mask_X = torch.zeros(B, n, dtype=torch.bool, device=data.X.device)
-    mask_E = torch.zeros(B, n, n, dtype=torch.bool, device=data.X.device)
-    if node_idx is not None:
-        for b in range(B):
-            mask_X[b, node_idx[b]] = True
-    if edge_idx is not None:
-        for b in range(B):
-            for bond in edge_idx[b]:
-                mask_E[b, bond[0], bond[1]] = True
-                mask_E[b, bond[1], bond[0]] = True
-    return mask_X, mask_E
+    dev = data.X.device
+    mask_X = torch.zeros(B, n, dtype=torch.uint8, device=dev)
+    mask_E = torch.zeros(B, n, n, dtype=torch.uint8, device=dev)
+    nodes, edges = inpaint_lists(node_idx, edge_idx, dev)
+    _inpaint(nodes, edges, B, n, mask_X=mask_X, mask_E=mask_E)
+    return mask_X.view(torch.bool), mask_E.view(torch.bool)
+
+
+def apply_inpainting(z_t, orig, nodes, edges):
+    """diffusion/sampling.py:44,177: z_t.X[mask_X], z_t.E[mask_E] = orig.X[mask_X], orig.E[mask_E], in place, from the index
+    tensors of inpaint_lists (work proportional to the lists, not to B n^2)."""
+    B, n, kx = z_t.X.shape
+    _inpaint(nodes, edges, B, n, kx, z_t.E.shape[-1], z=z_t, orig=orig)
+    return z_t
+
+
+def to_dense(data):
+    """graph.py:189-210 on the device: `data` carries the PyG batch fields x (N,kx), edge_index (2,M), edge_attr (M,ke), batch (N,
+    sorted), y and optionally mask_atom_mapping / mol_assignment (attributes or mapping keys).  The largest graph fixes n (one
+    host sync, at the data-loading boundary as in the reference)."""
+    get = (lambda k: data.get(k)) if isinstance(data, dict) else (lambda k: getattr(data, k, None))
+    x, batch = get('x').contiguous().float(), get('batch').contiguous().long()
+    dev = x.device
+    ei, ea = get('edge_index').contiguous().long(), get('edge_attr').contiguous().float()
+    am, mol = get('mask_atom_mapping'), get('mol_assignment')
+    N, kx = x.shape
+    M, ke = ea.shape
+    B = int(batch[-1].item()) + 1 if N else 0
+    n = int(torch.bincount(batch, minlength=B).max().item()) if N else 0
+    X = torch.empty(B, n, kx, device=dev); E = torch.empty(B, n, n, ke, device=dev)
+    nm = torch.empty(B, n, dtype=torch.uint8, device=dev)
+    amd = torch.empty(B, n, dtype=torch.int64, device=dev) if am is not None else None
+    mold = torch.empty(B, n, dtype=torch.int64, device=dev) if mol is not None else None
+    ptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    L.check(L.lib().da_to_dense(L.ptr(x), L.ptr(batch, torch.int64), L.ptr(ei, torch.int64), L.ptr(ea),
+                                L.ptr(am.contiguous().long() if am is not None else None), L.ptr(mol.contiguous().long() if mol is not None else None),
+                                N, M, B, n, kx, ke, L.ptr(X), L.ptr(E), L.ptr(nm), L.ptr(amd), L.ptr(mold), L.ptr(ptr), L.stream()), 'da_to_dense')
+    return PlaceHolder(X=X, E=E, y=get('y'), node_mask=nm.view(torch.bool), atom_map_numbers=amd, mol_assignments=mold)
 
 
 def duplicate_data(dense_data, n_samples=1, mask_=True, get_discrete_data=False):

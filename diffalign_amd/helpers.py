@@ -17,6 +17,16 @@ def exp_noise_like(shape, device, generator=None) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float32, device=device).exponential_(1.0, generator=generator)
 
 
+def counter_exp_noise(chain_seeds: torch.Tensor, call: int, B, n, kx, ke):
+    """Exp(1) race noise (B,n,kx), (B,n,n,ke) as a pure function of (chain seed, draw call, element): a chain's draws do not
+    depend on which batch or rank it runs in (C-ABI da_counter_exp_noise; distributed.chain_seed gives the seeds)."""
+    dev = chain_seeds.device
+    qX = torch.empty(B, n, kx, device=dev); qE = torch.empty(B, n, n, ke, device=dev)
+    L.check(L.lib().da_counter_exp_noise(L.ptr(chain_seeds.contiguous(), torch.int64), int(call), L.ptr(qX), L.ptr(qE), B, n, kx, ke,
+                                         L.stream()), 'da_counter_exp_noise')
+    return qX, qE
+
+
 def posterior_sample(pred_X, pred_E, z_t: PlaceHolder, Qt: PlaceHolder, Qsb: PlaceHolder, Qtb: PlaceHolder,
                      temperature=(1.0, 1.0), noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                      orig: Optional[PlaceHolder] = None, node_masks=None, want_prob=False, want_sample=True,

@@ -98,8 +98,47 @@ class PlaceHolder:
                     'da_mask_dense')
         return self
 
+    # ---- batch bookkeeping of the sampling / evaluation drivers (placeholder.py:104-152): plain tensor plumbing
+    def to_numpy(self):
+        return self._apply_inplace(lambda t: t.detach().cpu().numpy())
+
+    def reshape_bs_n_samples(self, bs, n_samples, n):
+        self.X, self.E = self.X.reshape(bs, n_samples, n), self.E.reshape(bs, n_samples, n, n)
+        self.y = torch.empty((bs, n_samples))
+        for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
+            setattr(self, name, getattr(self, name).reshape(bs, n_samples, n))
+
+    def pad_nodes(self, pad_size):
+        """Zero-pad the node axis (collapsed or one-hot X / E) by pad_size."""
+        import torch.nn.functional as F
+        self.X = F.pad(self.X, (0, pad_size) if self.X.ndim == 2 else (0, 0, 0, pad_size))
+        self.E = F.pad(self.E, (0, pad_size, 0, pad_size) if self.E.ndim == 3 else (0, 0, 0, pad_size, 0, pad_size))
+        for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
+            setattr(self, name, F.pad(getattr(self, name), (0, pad_size)))
+
+    def cat_by_batchdim(self, placeh):
+        for f in fields(self):
+            setattr(self, f.name, torch.cat((getattr(self, f.name), getattr(placeh, f.name)), dim=0))
+
+    def cat_by_batchdim_with_padding(self, placeh):
+        small, big = (placeh, self) if self.X.shape[1] > placeh.X.shape[1] else (self, placeh)
+        small.pad_nodes(big.X.shape[1] - small.X.shape[1])
+        big.cat_by_batchdim(small)
+        return big
+
+    def select_by_batch_idx(self, idx):
+        return PlaceHolder(**{f.name: getattr(self, f.name)[idx:idx + 1].clone() if isinstance(getattr(self, f.name), torch.Tensor) else None
+                              for f in fields(self)})
+
+    def select_by_batch_and_sample_idx(self, bs, n_samples, batch_idx, sample_idx):
+        assert self.X.ndim == 2 and self.E.ndim == 3, f'expected collapsed X (bs, n) / E (bs, n, n), got {self.X.shape} / {self.E.shape}'
+        pick = lambda t, *tail: t.reshape(bs, n_samples, *tail)[batch_idx:batch_idx + 1, sample_idx]
+        n = self.X.shape[1]
+        return PlaceHolder(X=pick(self.X, n), E=pick(self.E, n, n), y=pick(self.y, -1), node_mask=pick(self.node_mask, n),
+                           atom_map_numbers=pick(self.atom_map_numbers, n), mol_assignments=pick(self.mol_assignments, n))
+
     def serialize(self):
-        return {f.name: getattr(self, f.name).detach().cpu().numpy().tolist() for f in fields(self)}
+        return {f.name: (getattr(self, f.name).detach().cpu().numpy().tolist() if getattr(self, f.name) is not None else None) for f in fields(self)}
 
     @classmethod
     def deserialize(cls, data: dict) -> 'PlaceHolder':

@@ -14,9 +14,11 @@ from . import graph, helpers
 class SamplingMixin:
     @torch.no_grad()
     def sample_one_batch(self, device=None, n_samples=None, data=None, get_chains=False, get_true_rxns=False,
-                         inpaint_node_idx=None, inpaint_edge_idx=None, noise_fn=None):
+                         inpaint_node_idx=None, inpaint_edge_idx=None, noise_fn=None, chain_seeds=None):
         """noise_fn(call_index, shape) -> Exp(1) tensor makes the draws a function of explicit noise (tests); the
-        call order equals the reference's multinomial call order (X then E; limit draw first)."""
+        call order equals the reference's multinomial call order (X then E; limit draw first).
+        chain_seeds (B,) int64: per-chain counter-based noise (helpers.counter_exp_noise) -- every chain's draws depend on its
+        own seed only, so sharded runs give the same samples under any rank layout (diffalign_amd/distributed.py)."""
         assert data is not None, 'diffalign_amd samples conditionally: `data` (the dense condition) is required'
         if self.cfg.diffusion.classifier_free_guidance:
             raise NotImplementedError('classifier-free guidance is off in both align_* experiments and is not built')
@@ -28,7 +30,14 @@ class SamplingMixin:
         kx, ke = dense_data.X.shape[-1], dense_data.E.shape[-1]
         calls = [0]
 
+        if chain_seeds is not None:
+            assert noise_fn is None and chain_seeds.shape == (B,)
+            chain_seeds = chain_seeds.to(device=device, dtype=torch.int64)
+
         def nz():
+            if chain_seeds is not None:
+                calls[0] += 1
+                return helpers.counter_exp_noise(chain_seeds, calls[0] - 1, B, n, kx, ke)
             if noise_fn is None:
                 return None
             qx = noise_fn(calls[0], (B * n, kx)).reshape(B, n, kx).to(device)
@@ -43,14 +52,12 @@ class SamplingMixin:
                                      self.cfg.diffusion.mask_nodes, self.cfg.diffusion.mask_edges)
         z_t = graph.apply_mask(orig=dense_data, z_t=z_t, atom_decoder=self.dataset_info.atom_decoder,
                                bond_decoder=self.dataset_info.bond_decoder, node_masks=masks)
-        inpaint = inpaint_node_idx is not None or inpaint_edge_idx is not None
-        if inpaint:
-            fix_X, fix_E = graph.fix_nodes_and_edges_by_idx(dense_data, inpaint_node_idx, inpaint_edge_idx)
+        # inpainting (sampling.py:42-45,175-178): the index lists go to the device once; per step the listed rows / pairs are
+        # copied back from the condition by one scatter (the reference rebuilds dense masks from a deepcopy at every step)
+        fix_nodes, fix_edges = graph.inpaint_lists(inpaint_node_idx, inpaint_edge_idx, device)
 
         def fix(z):
-            if inpaint:
-                z.X = torch.where(fix_X[..., None], dense_data.X, z.X)
-                z.E = torch.where(fix_E[..., None], dense_data.E, z.E)
+            graph.apply_inpainting(z, dense_data, fix_nodes, fix_edges)
             if not self.cfg.diffusion.diffuse_edges: z.E = dense_data.E.clone()
             if not self.cfg.diffusion.diffuse_nodes: z.X = dense_data.X.clone()
             return z
@@ -59,15 +66,26 @@ class SamplingMixin:
         T_eval = self.cfg.diffusion.diffusion_steps_eval
         assert self.T % T_eval == 0, 'diffusion_steps_eval should be divisible by diffusion_steps'
         eval_step_size = self.T // T_eval
-        sample_chains = []
+        sample_chains, prob_s_chains, pred_0_chains = [], [], []
         temps = (float(self.cfg.diffusion.temperature_scaling_node), float(self.cfg.diffusion.temperature_scaling_edge))
         tm = self.transition_model_eval
+        log_every_t = int(getattr(getattr(self.cfg, 'train', None), 'log_every_t', 1) or 1)
         for t_int in range(T_eval, 0, -1):
             t_array = torch.full((B, 1), t_int, dtype=torch.long, device=device)
             z_t.y = t_array.float() * eval_step_size                       # raw train-scale step index (sampling.py:76)
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)
-            if get_chains:
+            s_int = t_int - 1
+            if get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1):       # sampling.py:120-161 (plotting chains)
                 sample_chains.append((t_int, z_t.get_new_object().mask(z_t.node_mask, collapse=True)))
+                p0 = pred.get_new_object(X=torch.softmax(pred.X, -1), E=torch.softmax(pred.E, -1))
+                p0.X[..., -1] = 0.                                         # SuNo predictions ignored (sampling.py:125-126)
+                p0.X /= p0.X.sum(-1, keepdim=True)
+                pX, pE, _, _ = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
+                                                        tm.get_Qt_bar(t_array), temperature=temps, want_prob=True, want_sample=False)
+                for chain, obj in ((pred_0_chains, p0), (prob_s_chains, z_t.get_new_object(X=pX, E=pE))):
+                    obj = graph.apply_mask(orig=dense_data, z_t=obj, atom_decoder=self.dataset_info.atom_decoder,
+                                           bond_decoder=self.dataset_info.bond_decoder, node_masks=masks)
+                    chain.append((s_int, fix(obj)))
             _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
                                                       tm.get_Qt_bar(t_array), temperature=temps, noise=nz(),
                                                       orig=dense_data, node_masks=masks)
@@ -76,7 +94,7 @@ class SamplingMixin:
         if get_chains:
             sample_chains.append((0, z_t.get_new_object().mask(z_t.node_mask, collapse=True)))
         if get_true_rxns:
-            return (z_t.mask(z_t.node_mask, collapse=True), sample_chains, [], [], dense_data)
+            return (z_t.mask(z_t.node_mask, collapse=True), sample_chains, prob_s_chains, pred_0_chains, dense_data)
         if get_chains:
-            return (z_t.mask(z_t.node_mask, collapse=True), sample_chains, [], [])
+            return (z_t.mask(z_t.node_mask, collapse=True), sample_chains, prob_s_chains, pred_0_chains)
         return z_t

@@ -44,6 +44,28 @@ int da_free_masks(const float* X_orig, const uint8_t* node_mask, const int64_t* 
 int da_apply_mask(float* zX, float* zE, const float* origX, const float* origE, const uint8_t* mask_x,
                   const uint8_t* mask_e, int B, int n, int kx, int ke, int as_logits, void* stream);
 
+/* Dense conversion of a PyG-style sparse batch on the device: to_dense_batch / to_dense_adj + encode_no_element.
+ * Replaces diffalign/utils/graph.py:189-210 (to_dense).  x (N,kx) node features of all graphs, batch (N) sorted graph index per
+ * node, edge_index (2,M) global node indices, edge_attr (M,ke), atom_map / mol_assignment (N) int64 (nullable).  Outputs, n =
+ * largest graph: X (B,n,kx), E (B,n,n,ke) (self loops dropped, duplicate edges add up, then any all-zero row / pair gets class 0),
+ * node_mask (B,n), atom_map_dense / mol_dense (B,n) (nullable).  ptr = (B+1) int64 of caller-owned scratch (row offsets). */
+int da_to_dense(const float* x, const int64_t* batch, const int64_t* edge_index, const float* edge_attr, const int64_t* atom_map,
+                const int64_t* mol_assignment, long long N, long long M, int B, int n, int kx, int ke, float* X, float* E,
+                uint8_t* node_mask, int64_t* atom_map_dense, int64_t* mol_dense, int64_t* ptr, void* stream);
+
+/* Inpainting from index lists: nodes (n_nodes,2) int32 rows (b,i), edges (n_edges,3) int32 rows (b,i,j) (both orientations are
+ * touched).  mask_X (B,n) / mask_E (B,n,n) uint8, nullable: set to 1 at the listed entries (the masks of
+ * diffalign/utils/graph.py:621-656 fix_nodes_and_edges_by_idx; the caller zero-fills them).  zX / zE, nullable: the listed rows /
+ * pairs take orig's values (diffusion/sampling.py:42-45,175-178).  Work is O(list length), not O(B n^2). */
+int da_inpaint(const int* nodes, int n_nodes, const int* edges, int n_edges, uint8_t* mask_X, uint8_t* mask_E, float* zX, float* zE,
+               const float* orig_X, const float* orig_E, int B, int n, int kx, int ke, void* stream);
+
+/* Exp(1) race noise as a pure function of (chain seed, draw call, element index within the chain): noise_X (B,n,kx) for stream
+ * 2*call, noise_E (B,n,n,ke) for stream 2*call+1, chain_seeds (B) int64.  No counterpart in the reference (it draws from torch's
+ * global generator); this is what makes sharded sampling independent of the rank layout (diffalign_amd/distributed.py). */
+int da_counter_exp_noise(const int64_t* chain_seeds, long long call, float* noise_X, float* noise_E, int B, int n, int kx, int ke,
+                         void* stream);
+
 /* ---- L1 diffusion math ---------------------------------------------------------------------------------------- */
 
 /* One fused reverse step:  pred = log_softmax(logits)*temperature  (diffusion/sampling.py:82)

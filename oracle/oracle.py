@@ -530,10 +530,73 @@ def ce_loss(logits_X, logits_E, true_X, true_E, mask_x, mask_e, lambda_E: float)
 # --------------------------------------------------------------------------------------
 # a16 full reverse-diffusion chain (diffusion/sampling.py:11-197) with explicit noise
 # --------------------------------------------------------------------------------------
+def fix_masks(B: int, n: int, node_idx, edge_idx) -> Tuple[Tensor, Tensor]:
+    """utils/graph.py:621-656 fix_nodes_and_edges_by_idx: (B,n) / (B,n,n) bool masks from per-graph index lists."""
+    mX = torch.zeros(B, n, dtype=torch.bool); mE = torch.zeros(B, n, n, dtype=torch.bool)
+    if node_idx is not None:
+        for b in range(B):
+            mX[b, node_idx[b]] = True
+    if edge_idx is not None:
+        for b in range(B):
+            for i, j in edge_idx[b]:
+                mE[b, i, j] = True; mE[b, j, i] = True
+    return mX, mE
+
+
+def duplicate(d: Dict[str, Tensor], n_samples: int, mask_: bool = True) -> Dict[str, Tensor]:
+    """utils/graph.py:130-158 duplicate_data: .mask() then repeat_interleave of every field along the batch axis."""
+    d = dict(d)
+    if mask_:
+        d['X'], d['E'] = mask_dense(d['X'], d['E'], d['node_mask'])
+    return {k: (v.repeat_interleave(n_samples, dim=0) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def to_dense(x: Tensor, batch: Tensor, edge_index: Tensor, edge_attr: Tensor, atom_map: Optional[Tensor] = None,
+             mol: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """utils/graph.py:189-210 to_dense: to_dense_batch (rows of graph b, in order, padded to the largest graph),
+    remove_self_loops, to_dense_adj (adj[b, i - ptr_b, j - ptr_b] += edge_attr), encode_no_element on X and E."""
+    B = int(batch.max()) + 1
+    counts = torch.bincount(batch, minlength=B)
+    n = int(counts.max())
+    ptr = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(batch.numel()) - ptr[batch]
+    X = x.new_zeros(B, n, x.shape[1]); X[batch, pos] = x
+    nm = torch.zeros(B, n, dtype=torch.bool); nm[batch, pos] = True
+    keep = edge_index[0] != edge_index[1]
+    ei, ea = edge_index[:, keep], edge_attr[keep]
+    E = edge_attr.new_zeros(B, n, n, edge_attr.shape[1])
+    b = batch[ei[0]]
+    E.index_put_((b, ei[0] - ptr[b], ei[1] - ptr[b]), ea, accumulate=True)
+    out = dict(X=encode_no_element(X), E=encode_no_element(E), node_mask=nm)
+    for name, v in (('atom_map_numbers', atom_map), ('mol_assignments', mol)):
+        if v is not None:
+            d_ = v.new_zeros(B, n); d_[batch, pos] = v
+            out[name] = d_
+    return out
+
+
+def counter_exp_noise(seeds: Tensor, call: int, n: int, kx: int, ke: int) -> Tuple[Tensor, Tensor]:
+    """Exp(1) noise as a function of (chain seed, draw call, element): the integers of csrc/k_graph.hip counter_exp (numpy
+    uint64, wrap-around arithmetic); no counterpart in the reference."""
+    def stream(st, per):
+        with np.errstate(over='ignore'):
+            sd = seeds.numpy().astype(np.int64).view(np.uint64)[:, None]
+            z = sd + np.uint64(0x9E3779B97F4A7C15) * np.uint64(st + 1)
+            z = z ^ (np.arange(per, dtype=np.uint64)[None, :] * np.uint64(0xD1B54A32D192ED03))
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        u = ((z >> np.uint64(40)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+        return torch.from_numpy(-np.log(u))
+    B = seeds.shape[0]
+    return stream(2 * call, n * kx).reshape(B, n, kx), stream(2 * call + 1, n * n * ke).reshape(B, n, n, ke)
+
+
 def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tensor], T: int, T_eval: int, mask_mode: str,
-                 suno_idx: int, noise_fn, temp=(1.0, 1.0)):
+                 suno_idx: int, noise_fn, temp=(1.0, 1.0), node_idx=None, edge_idx=None):
     """forward_fn(zX, zE, y) -> (logits_X, logits_E).  noise_fn(call_index, shape) -> Exp(1) noise; calls are numbered
-    in the reference's multinomial order: limit draw (X, E), then per step (X, E)."""
+    in the reference's multinomial order: limit draw (X, E), then per step (X, E).  node_idx / edge_idx: inpainting lists
+    (sampling.py:42-45,175-178: the listed nodes / edges are copied back from the condition after every draw)."""
     X0, E0, nm = true['X'], true['E'], true['node_mask']
     B, n, Kx = X0.shape
     Ke = E0.shape[-1]
@@ -543,6 +606,12 @@ def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tenso
     c += 2
     mx, me = free_masks(X0, nm, true.get('atom_map_numbers'), mask_mode, suno_idx)
     zX, zE = apply_mask(X0, E0, zX, zE, mx, me)
+    fX, fE = fix_masks(B, n, node_idx, edge_idx)
+
+    def fix(zX, zE):
+        return torch.where(fX[..., None], X0, zX), torch.where(fE[..., None], E0, zE)
+
+    zX, zE = fix(zX, zE)
     step = T // T_eval
     for t in range(T_eval, 0, -1):
         y = torch.full((B, 1), float(t * step))
@@ -551,6 +620,7 @@ def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tenso
         qE = noise_fn(c + 1, (B * n * n, Ke)).reshape(B, n, n, Ke)
         c += 2
         _, _, zX, zE = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
+        zX, zE = fix(zX, zE)
     return zX, zE
 
 

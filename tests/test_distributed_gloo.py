@@ -58,6 +58,68 @@ def test_two_rank_sharded_sampling_equals_single_rank(tmp_path):
     assert torch.equal(X, ref[0]) and torch.equal(E, ref[1])
 
 
+class _Cond:
+    """Minimal dense condition for the sharded driver (CPU)."""
+    def __init__(self, X, E):
+        self.X, self.E = X, E
+
+    def get_new_object(self):
+        return _Cond(self.X.clone(), self.E.clone())
+
+
+def _stub_sample_for_condition(dense_data, n_samples, inpaint_node_idx, inpaint_edge_idx, chain_seeds):
+    """Stands in for DiscreteDenoisingDiffusionRxn.sample_for_condition on the CPU: 'samples' that are a deterministic function
+    of the condition and of each chain's own counter-based noise (oracle.counter_exp_noise) -- as the real chains are."""
+    from types import SimpleNamespace
+    from oracle import oracle as O
+    n = dense_data.X.shape[1]
+    assert chain_seeds.shape == (n_samples,)
+    qX, qE = O.counter_exp_noise(chain_seeds, 0, n, 29, 7)
+    X = (1.0 / qX).argmax(-1) + dense_data.X.argmax(-1)                      # (k, n)
+    E = (1.0 / qE).argmax(-1)
+    E = torch.triu(E, 1); E = E + E.transpose(1, 2)
+    if inpaint_node_idx is not None:
+        X[:, inpaint_node_idx[0]] = 99
+    return SimpleNamespace(X=X, E=E)
+
+
+def _conditions():
+    g = torch.Generator().manual_seed(3)
+    sizes = [6, 9, 4]
+    return [_Cond(torch.nn.functional.one_hot(torch.randint(0, 29, (1, n), generator=g), 29).float(), torch.zeros(1, n, n, 7)) for n in sizes]
+
+
+def _cond_worker(rank, world, port, out, n_cond, n_samples):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from diffalign_amd.distributed import sample_conditions_sharded
+    res = sample_conditions_sharded(_conditions()[:n_cond], n_samples, _stub_sample_for_condition, seed=11,
+                                    inpaint_node_idx=[[0], [1, 2], []][:n_cond])
+    if rank == 0:
+        torch.save(res, out)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_condition_sampling_equals_single_rank(tmp_path):
+    """BASELINE configs[2] driver: (condition, sample) units cut over 2 ranks mid-condition, per-chain seeds, ragged condition
+    sizes padded for the gather -> the same samples as one rank; and fewer chains than ranks (one rank's shard is empty)."""
+    from diffalign_amd.distributed import sample_conditions_sharded
+    for k, (n_cond, n_samples) in enumerate([(3, 5), (1, 1)]):
+        ref = sample_conditions_sharded(_conditions()[:n_cond], n_samples, _stub_sample_for_condition, seed=11,
+                                        inpaint_node_idx=[[0], [1, 2], []][:n_cond])
+        assert ref[0].shape == (n_cond * n_samples, max([6, 9, 4][:n_cond])) and ref[0].dtype == torch.uint8
+        out = str(tmp_path / f'c{k}.pt')
+        port = 33500 + (os.getpid() % 2000) + k
+        mp.spawn(_cond_worker, args=(2, port, out, n_cond, n_samples), nprocs=2, join=True)
+        X, E = torch.load(out)
+        assert torch.equal(X, ref[0]) and torch.equal(E, ref[1])
+    assert (ref[0][0, 0] == 99)
+
+
 def _grad_worker(rank, world, port, out):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))

@@ -60,7 +60,9 @@ def test_chain_config0_against_reference_golden():
     out = model.sample_one_batch(data=data, noise_fn=lambda c, shp: counter_noise(shp, c))
     gx, ge = out.X.argmax(-1).cpu().numpy(), out.E.argmax(-1).cpu().numpy()
     ax, ae = (gx == z['chain_X']).mean(), (ge == z['chain_E']).mean()
-    assert ax >= 0.9 and ae >= 0.97, (ax, ae)
+    print(f'config-0 chain vs reference: nodes {ax:.4f}, edges {ae:.4f}')
+    # measured: nodes 1.0000, edges >= 0.998 (a handful of near-tie edge draws flip under bf16 logits and propagate)
+    assert ax >= 0.98 and ae >= 0.99, (ax, ae)
     assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
 
 
@@ -140,3 +142,45 @@ def test_marginal_sampling_at_twice_max_atoms():
     assert not bool(((a.X.cpu().argmax(-1) == 28) & free).any()) and not bool(((a.X.cpu().argmax(-1) == 0) & free).any())
     fee = free[:, :, None] & free[:, None, :]
     assert not bool((a.E.cpu().argmax(-1)[fee] >= 4).any())
+
+
+def test_config2_shape_100_steps_100_samples_one_condition():
+    """BASELINE.json configs[2] on one GPU: sample_for_condition with 100 samples of one condition at n = 300, the full 9-layer
+    align_absorbing denoiser, T = 500 / 100 evaluation steps, extra features and Laplacian positional encodings computed on the
+    device (nothing is an injected input).  No reference run exists at this size (no checkpoint offline), so the checks are the
+    size-independent properties: collapsed symmetric output, the condition untouched, padding stays class 0, chains with
+    different seeds differ, and the same seeds give the same 100 chains in a second run."""
+    from diffalign_amd.diffusion_rxn import DiscreteDenoisingDiffusionRxn
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd.distributed import chain_seed
+    from diffalign_amd import synthetic as S
+    from tests.golden.common import extra_info
+    dims = dict(n_layers=9, hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
+                hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
+    torch.manual_seed(0)
+    cfg = make_cfg(dims, T_=500, T_eval=100, extra=True)
+    cfg.neuralnet.num_lap_eig_vectors = 20
+    cfg.train.log_every_t = 50
+    info = make_info()
+    for k, v in vars(extra_info(ns)).items():
+        setattr(info, k, v)
+    model = DiscreteDenoisingDiffusionRxn(cfg, info, device=D).eval()
+    n, n_samples = 300, 100
+    true = S.make_reaction_batch(1, n, seed=17, P=30)                     # a USPTO-sized product (30 atoms) padded to MAX_ATOMS_RXN
+    seeds = torch.tensor([chain_seed(1, g) for g in range(n_samples)], dtype=torch.int64)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(123)          # the random signs of the Laplacian encodings and the eigen-features' noise on padded slots
+        cond = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+        runs.append(model.sample_for_condition(dense_data=cond, n_samples=n_samples, inpaint_node_idx=None, inpaint_edge_idx=None,
+                                               chain_seeds=seeds))
+    a, b = runs
+    assert a.X.shape == (n_samples, n) and a.E.shape == (n_samples, n, n)
+    assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E)
+    assert torch.equal(a.E, a.E.transpose(1, 2))
+    cls, ecl = true['X'][0].argmax(-1), true['E'][0].argmax(-1)
+    s = int((cls == 28).nonzero()[0])
+    assert torch.equal(a.X.cpu()[:, s:], cls[s:].expand(n_samples, -1))
+    assert torch.equal(a.E.cpu()[:, s:, :], ecl[s:, :].expand(n_samples, -1, -1))
+    assert bool((a.X.cpu()[:, ~true['node_mask'][0]] == 0).all())
+    assert len({tuple(r.tolist()) for r in a.X.cpu()[:, :s]}) > 1         # chains are not copies of each other

@@ -184,6 +184,65 @@ def test_single_step_logits_and_chain_config0():
     assert np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
 
 
+def test_graph_utils_fix_duplicate_to_dense():
+    """utils/graph.py fix_nodes_and_edges_by_idx / duplicate_data / to_dense against the reference's outputs."""
+    z = load('graph_utils')
+    mX, mE = O.fix_masks(3, 24, [[0, 1, 5], [2], []], [[[0, 1], [1, 5]], [[2, 3]], []])
+    assert np.array_equal(mX.numpy(), z['fix_mask_X']) and np.array_equal(mE.numpy(), z['fix_mask_E'])
+    d = dict(X=T(z['dup_in_X']), E=F.one_hot(T(z['fix_E_idx']), KE).float(), node_mask=T(z['fix_node_mask']), y=torch.zeros(3, 1))
+    dd = O.duplicate(d, 3)
+    close(dd['X'], z['dup_X'], 0); assert np.array_equal(dd['E'].argmax(-1).numpy(), z['dup_E_idx'])
+    assert np.array_equal(dd['node_mask'].numpy(), z['dup_node_mask'])
+    cX, cE = O.collapse_dense(dd['X'], dd['E'], dd['node_mask'])
+    assert np.array_equal(cX.numpy(), z['dup_disc_X']) and np.array_equal(cE.numpy(), z['dup_disc_E'])
+    td = O.to_dense(F.one_hot(T(z['td_x']), KX).float(), T(z['td_batch']), T(z['td_edge_index']), F.one_hot(T(z['td_edge_attr']), KE).float(),
+                    T(z['td_am']), T(z['td_mol']))
+    close(td['X'], z['td_X'], 0); close(td['E'], z['td_E'], 0)
+    assert np.array_equal(td['node_mask'].numpy(), z['td_node_mask'])
+    assert np.array_equal(td['atom_map_numbers'].numpy(), z['td_am_dense']) and np.array_equal(td['mol_assignments'].numpy(), z['td_mol_dense'])
+
+
+INPAINT_NODES = [[0, 1, 2], [3], [], [0, 4]]
+INPAINT_EDGES = [[[0, 1], [1, 2]], [], [[1, 2]], [[0, 4]]]
+
+
+def test_inpainting_chain_and_sample_for_condition():
+    """sample_one_batch with inpainting lists and sample_for_condition (2 conditions x 3 samples): reproduced bit for bit."""
+    from diffalign_amd import synthetic as S
+    zi = load('inpaint_tiny')
+    z, sd, true, fwd = _tiny_setup()
+    assert np.array_equal(zi['true_X'], z['true_X'])
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    zX, zE = O.sample_chain(fwd, true, tabs, 10, 10, 'product_and_sn', 28, lambda c, shp: counter_noise(shp, c), node_idx=INPAINT_NODES,
+                            edge_idx=INPAINT_EDGES)
+    assert np.array_equal(zX.argmax(-1).numpy(), zi['inp_X']) and np.array_equal(zE.argmax(-1).numpy(), zi['inp_E'])
+    for b, idx in enumerate(INPAINT_NODES):                               # the property inpainting exists for
+        assert torch.equal(zX[b, idx], true['X'][b, idx])
+    dup = O.duplicate({k: v[:2] for k, v in true.items()}, 3)
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=dup['atom_map_numbers']), 64, seed=73)
+
+    def fwd6(zX, zE, y):
+        r = O.denoiser_forward(sd, zX, zE, y, dup['node_mask'], int(z['n_layers']), int(z['n_head']), (KX, KE, 1), dup['atom_map_numbers'], pos,
+                               dup['mol_assignments'], True)
+        return r[0], r[1]
+    rep = lambda idx: [i for i in idx for _ in range(3)]
+    sX, sE = O.sample_chain(fwd6, dup, tabs, 10, 10, 'product_and_sn', 28, lambda c, shp: counter_noise(shp, 100 + c),
+                            node_idx=rep([[0, 1], []]), edge_idx=rep([[[0, 1]], []]))
+    cX, cE = O.collapse_dense(sX, sE, dup['node_mask'])
+    assert np.array_equal(cX.numpy(), zi['sfc_X']) and np.array_equal(cE.numpy(), zi['sfc_E'])
+
+
+def test_counter_noise_is_exponential_and_layout_free():
+    seeds = torch.tensor([5, 123456789012, -7], dtype=torch.int64)
+    qX, qE = O.counter_exp_noise(seeds, 3, 40, KX, KE)
+    assert qX.shape == (3, 40, KX) and qE.shape == (3, 40, 40, KE) and (qE > 0).all() and torch.isfinite(qE).all()
+    assert abs(qE.mean().item() - 1.0) < 0.02 and abs(qE.var().item() - 1.0) < 0.05          # Exp(1)
+    a, _ = O.counter_exp_noise(seeds[1:2], 3, 40, KX, KE)
+    assert torch.equal(a[0], qX[1])                                       # a chain's noise does not depend on its batch position
+    b, _ = O.counter_exp_noise(seeds, 4, 40, KX, KE)
+    assert not torch.equal(b, qX)
+
+
 @pytest.mark.parametrize('case', ['rxn_true', 'rxn_t5', 'conn', 'dense', 'sparse'])
 def test_extra_features(case):
     """a8: oracle restatement of ExtraFeatures('all') + ExtraMolecularFeatures vs the reference's outputs."""
