@@ -105,6 +105,10 @@ def main():
     ap.add_argument('--extra-features', choices=['inputs', 'device'], default='inputs',
                     help="'inputs' (default, SURVEY §8d: the 8 + 12 extra features are given); 'device': computed inside the step "
                          '(csrc/k_extra.hip + the batched partial eigensolver of csrc/k_extra_eig.hip), as a real sampling loop does')
+    ap.add_argument('--workload', choices=['full', 'uspto_like'], default='full',
+                    help="'full' (default, the headline: every graph has 299 real nodes, BASELINE.json configs[1]); 'uspto_like': product "
+                         'sizes P ~ clip(N(26,10), 5, 142) padded to --nodes (SURVEY 8d), i.e. what a real USPTO batch looks like: most '
+                         'pairs are padding and take the edge kernel\'s dead-tile path')
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
@@ -142,7 +146,7 @@ def main():
     B, n = args.batch, args.nodes
     torch.manual_seed(0)                                      # weights: default nn.Linear/LayerNorm init, seed 0
     model = DiscreteDenoisingDiffusion(make_cfg(FULL), make_info(), device=dev).eval()
-    P = (n - S.NB_DUMMY - 1) // 2
+    P = (n - S.NB_DUMMY - 1) // 2 if args.workload == 'full' else None
     true = S.make_reaction_batch(B, n, seed=1 + rank, P=P)    # this rank's shard of conditions x samples
     data = PlaceHolder(**{k: v.to(dev) for k, v in true.items()})
     pos = S.shared_pos_encodings(true, 256, seed=3).to(dev)
@@ -223,7 +227,7 @@ def main():
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'edge_layer_traffic.json')) as f:
             tj = json.load(f)
-        if tj['workload'] == {'B': B, 'n': n}:
+        if tj['workload'] == {'B': B, 'n': n} and args.workload == 'full':
             traffic = tj['hbm_bytes_per_launch']
             if engine.STATS_TAIL and 'with_stats_tail' in tj:   # layers >= 1 run the kernel with its statistics tail
                 nl = len(model.model.tf_layers)
@@ -242,8 +246,10 @@ def main():
         out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-               'config': {'workload': f'align_absorbing denoiser forward + posterior/sample/mask, batch {B}/GPU padded to n={n} '
-                                      '(BASELINE.json configs[1]), 9 layers, 8.18M params, random-init weights',
+               'config': {'workload': (f'align_absorbing denoiser forward + posterior/sample/mask, batch {B}/GPU padded to n={n} '
+                                       '(BASELINE.json configs[1]), 9 layers, 8.18M params, random-init weights' if args.workload == 'full' else
+                                       f'NOT the headline -- USPTO-like product sizes (P ~ N(26,10), {float(true["node_mask"].float().mean()):.0%} real '
+                                       f'nodes) padded to n={n}, batch {B}/GPU, same network and step'),
                           'extra_features': 'given as inputs (SURVEY 8d)' if args.extra_features == 'inputs' else 'computed on the device inside the step',
                           'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)'},
                'roofline': roof}

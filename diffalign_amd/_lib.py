@@ -58,7 +58,7 @@ SIGNATURES = {
     'da_kv_pack': 'i:ppipiiip',
     'da_edge_layer': 'i:pppippppppppfiiiiipqp',
     'da_edge_layer_stats': 'i:pppippppppppfiiiiipqpipp',
-    'da_edge_layer_tuning': 'i:iiiii',
+    'da_edge_layer_tuning': 'i:iiiiii',
     'da_edge_split_scratch_bytes': 'q:iii',
     'da_edge_stats': 'i:ppiiiip',
     'da_x_stats': 'i:ppiiiip',

@@ -86,6 +86,7 @@ struct EdgeLayerArgs {
   int stagger, prio;      // waves NW/2.. start `stagger`*64 cycles late / run at s_setprio 1 (breaks SIMD-partner lockstep)
   int skew;               // the older half of a workgroup's waves takes `skew` whole rows more, the younger half as many fewer
   int tail_old;           // the runs of the split rows all go to the older half
+  int skip_dead;          // tiles without a single real pair (padded query row, or 32 padded keys) skip the attention part
   float* stats;           // Etoy statistics partials of E_in, k_e_stats' layout [B][stats_nchunk][4][DE], or null
   int stats_nchunk;
   int* ticket;            // work counter of the statistics tail (zero on entry)
@@ -147,10 +148,14 @@ template <int DE, int DX, int DFF>
 __device__ __forceinline__ void gemm2_block(const int cb, const int lane, const f32x16& z, const uint4* sWO, const bf16x8 id0,
                                             const bf16x8 id1, f32x16 (&acc2)[DE / 32]) {
   using C = EdgeCfg<DE, DX, DFF>;
+#ifdef EXP_NOTRANSPOSE
+  const bf16x8 zb0 = pack_acc(z, 0), zb1 = pack_acc(z, 1);          // timing experiment: what the identity-MFMA transpose costs
+#else
   f32x16 zt = splat16(0.f);
   zt = mfma32(pack_acc(z, 0), id0, zt);
   zt = mfma32(pack_acc(z, 1), id1, zt);
   const bf16x8 zb0 = pack_acc(zt, 0), zb1 = pack_acc(zt, 1);
+#endif
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
     acc2[mt] = mfma32(LDSF(sWO, (cb * C::MT + mt) * 2 + 0, lane), zb0, acc2[mt]);
@@ -431,6 +436,29 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 
       const uint4* kvt = kvrow + (size_t)jt * C::NCB * 4 * 64;
       const uint4* kvn = (jt + 1 < NT) ? kvt + C::NCB * 4 * 64 : kvt;   // last tile: harmless reload
+      // A tile without one real pair (padded query row, or 32 padded / missing keys: most of a USPTO-sized graph padded to
+      // MAX_ATOMS_RXN) needs no attention work: newE is masked to zero there, so E' = LN2(FFN(LN1(E))) comes from the tile's
+      // epilogue alone, and its keys enter the per-channel softmax with score 0 and V = 0 (layers.py:254: no key mask), i.e. as
+      // count * exp(0 - m) in the denominator: a closed form per channel block instead of GEMM1 / exp / GEMM2 for 32 x 256 values.
+      const bool dead = a.skip_dead && (!mi || nm_all == 0u);          // wave-uniform
+      if (dead) {
+        const float cnt = (float)__popc(vbits & 0x0f0f0f0fu);          // valid key rows of this lane half
+        if (cnt > 0.f) {
+          constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+          for (int cb = 0; cb < C::NCB; ++cb) {
+            const float yv = -sP[C::P_BA + 32 * cb + r];               // score 0 in the kernel's shifted domain (y' = y - b_add)
+            const float mnew = fmaxf(sm_m[cb], yv), mref2 = mnew * LOG2E;
+            const float sc = __builtin_amdgcn_exp2f(fmaf(sm_m[cb], LOG2E, -mref2));
+            const float pz = __builtin_amdgcn_exp2f(fmaf(yv, LOG2E, -mref2));
+            sm_l[cb] = fmaf(sm_l[cb], sc, cnt * pz);
+            sm_a[cb] *= sc;
+            sm_m[cb] = mnew;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kvA[e] = kvn[e * 64];               // the K/V pipeline expects block 0 of the next tile
+      } else {
       // Channel blocks, software pipelined: GEMM1 of block cb+1 is issued beside the elementwise work of block cb, so the
       // wave's own MFMAs and VALU overlap (the two waves of a SIMD do not hide each other's dependency stalls).
       f32x16 e1, e2;
@@ -461,6 +489,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      }   // !dead
       __builtin_amdgcn_sched_barrier(0);
       STAMP(2)   // channel-block loop
       // ---- epilogue of the tile: newE^T + bias, pair mask, residual, LN1
@@ -734,7 +763,7 @@ static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s
 // Tuning knobs of the launch (-1 = choose automatically).  Read from the environment once (DA_EDGE_THREADS, DA_EDGE_SKEW,
 // DA_EDGE_TAIL_OLD, DA_EDGE_STAGGER, DA_EDGE_PRIO) and settable through da_edge_layer_tuning (tests, A/B timing).  Process-wide:
 // change them only while no other thread is inside da_edge_layer.
-struct EdgeTuning { int threads, skew, tail_old, stagger, prio; };
+struct EdgeTuning { int threads, skew, tail_old, stagger, prio, skip_dead; };
 static EdgeTuning& edge_tuning() {
   static EdgeTuning t = [] {
     auto env = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
@@ -742,6 +771,7 @@ static EdgeTuning& edge_tuning() {
     u.threads = env("DA_EDGE_THREADS", 512) == 256 ? 256 : 512;   // default: 8 waves/workgroup = 2 waves per SIMD
     u.skew = env("DA_EDGE_SKEW", -1); u.tail_old = env("DA_EDGE_TAIL_OLD", -1);
     u.stagger = env("DA_EDGE_STAGGER", 0); u.prio = env("DA_EDGE_PRIO", 0);
+    u.skip_dead = env("DA_EDGE_SKIP_DEAD", 1) != 0;
     return u;
   }();
   return t;
@@ -768,14 +798,15 @@ static int edge_max_rem(int rows, int n) {
 
 extern "C" {
 
-// Launch tuning of da_edge_layer (see EdgeTuning): threads 256 | 512 (0 = keep), skew / tail_old -1 = automatic, stagger, prio.
+// Launch tuning of da_edge_layer (see EdgeTuning): threads 256 | 512 (0 = keep), skew / tail_old -1 = automatic, stagger, prio,
+// skip_dead (1: tiles without a real pair take the closed form, 0: every tile runs the attention part).
 // da_edge_split_scratch_bytes depends on `threads`: size the scratch after this call.
-int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio) {
+int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio, int skip_dead) {
   DA_CHECK_ARG(threads == 0 || threads == 256 || threads == 512, "da_edge_layer_tuning: threads must be 0 (keep), 256 or 512");
   DA_CHECK_ARG(skew >= -1 && tail_old >= -1 && tail_old <= 1 && stagger >= 0 && prio >= 0 && prio <= 3, "da_edge_layer_tuning: bad value");
   EdgeTuning& t = edge_tuning();
   if (threads) t.threads = threads;
-  t.skew = skew; t.tail_old = tail_old; t.stagger = stagger; t.prio = prio;
+  t.skew = skew; t.tail_old = tail_old; t.stagger = stagger; t.prio = prio; t.skip_dead = skip_dead != 0;
   return DA_OK;
 }
 
@@ -821,9 +852,9 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, stats, stats_nchunk, ticket};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, 1, stats, stats_nchunk, ticket};
   { const EdgeTuning tune = edge_tuning();
-    a.stagger = tune.stagger; a.prio = tune.prio;
+    a.stagger = tune.stagger; a.prio = tune.prio; a.skip_dead = tune.skip_dead;
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
     // default shares: ~57 % of a SIMD pair's tiles to the older wave (the per-slot run times of the EXP_STAMP build cross there:
     // older 2067 + 209 s, younger 2595 - 162 s k-cycles for s rows of skew at 9 rows per wave), from whole rows of skew plus,

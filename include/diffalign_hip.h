@@ -212,7 +212,8 @@ int da_kv_pack(const float* K, const float* V, int ldkv, void* kv_frag, int B, i
 /* The fused edge side of one XEyTransformerLayer: NodeEdgeBlock (layers.py:204-284) + the E branch of
  * XEyTransformerLayer.forward (layers.py:343-355) in one pass over E: E1/E2 projections, Y, per-channel softmax over
  * keys (no key mask, as the reference), weighted V, FiLM, e_out, LN1, FFN, LN2.  Also writes newX_in = yx1 + yx2p1*wV,
- * the input of x_out.  E_in != E_out. */
+ * the input of x_out, for the rows of real query nodes; rows of padded query nodes hold finite don't-care values (x_out's
+ * result is masked to zero there, layers.py:273).  E_in != E_out. */
 int da_edge_layer(const void* E_in, void* E_out, const float* Q, int ldq, const void* kv_frag, const uint8_t* node_mask,
                   const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                   const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch /* nullable */,
@@ -229,10 +230,11 @@ int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, 
 /* Launch tuning of da_edge_layer / da_edge_layer_stats, process-wide (no counterpart in the reference; for tests and A/B timing):
  * threads per workgroup 256 | 512 (0 = keep), skew = whole rows the older wave of every SIMD pair takes more than the younger one,
  * tail_old = the split rows' runs go to the older waves only (both: -1 = chosen from the problem size), stagger, prio = start
- * delay / s_setprio level of the younger half.  Results do not depend on any of them beyond the fp32 order of the softmax merge of
- * split rows.  da_edge_split_scratch_bytes depends on `threads`.  Defaults come from DA_EDGE_THREADS / _SKEW / _TAIL_OLD /
- * _STAGGER / _PRIO, read once. */
-int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio);
+ * delay / s_setprio level of the younger half, skip_dead = tiles without one real pair (padded query row, 32 padded keys) skip
+ * the attention arithmetic and enter the softmax in closed form (default 1).  Results do not depend on any of them beyond the fp32
+ * order of the softmax sums (split rows, dead tiles); E_out is bit-identical under all of them.  da_edge_split_scratch_bytes depends on `threads`.  Defaults come from DA_EDGE_THREADS / _SKEW / _TAIL_OLD /
+ * _STAGGER / _PRIO / _SKIP_DEAD, read once. */
+int da_edge_layer_tuning(int threads, int skew, int tail_old, int stagger, int prio, int skip_dead);
 /* Load balance of da_edge_layer's persistent grid: with a scratch of this many bytes (0: not needed for this size) the
  * query rows of the last, incomplete round are cut into runs of key tiles over all waves and folded by a small second
  * kernel; without it (NULL) whole rows only.  Results are identical up to the fp32 order of the softmax merge. */
