@@ -225,7 +225,7 @@ def main():
     # MI355X_MICROARCH.md), valid for the workload they were taken on only
     traffic = None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'edge_layer_traffic.json')) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02', 'edge_layer_traffic.json')) as f:
             tj = json.load(f)
         if tj['workload'] == {'B': B, 'n': n} and args.workload == 'full':
             traffic = tj['hbm_bytes_per_launch']
