@@ -37,6 +37,13 @@ SIGNATURES = {
     'da_masked_sums': 'i:pppppiip',
     'da_ce_grad': 'i:pppppppffppiiiip',
     'da_skip_grad': 'i:pppipippiiiip',
+    'da_attn_core_fwd': 'i:ppppppppfppppiiip',
+    'da_attn_core_bwd': 'i:pppppppfppppppppppppiiip',
+    'da_layernorm_bwd': 'i:ppppppqip',
+    'da_pool_stats_fwd': 'i:pppiiip',
+    'da_pool_stats_bwd': 'i:pppppiiip',
+    'da_vb_grad': 'i:ppppppppppppppffppiiiip',
+    'da_adamw': 'i:pppppqfffffifp',
     'da_edge_blob_bytes': 'q:iii',
     'da_edge_in_blob_bytes': 'q:ii',
     'da_edge_out_blob_bytes': 'q:ii',
@@ -116,6 +123,15 @@ def check(rc: int, what: str) -> None:
     _held.clear()
     if rc != 0:
         raise DiffAlignHipError(f'{what} failed (rc={rc}): {lib().da_last_error().decode()}')
+
+
+def last_error() -> str:
+    return lib().da_last_error().decode()
+
+
+# Bumped by whoever rewrites parameter storage behind torch's back (optim.FlatAdamW.step: one HIP kernel over the flat buffer, which
+# torch's per-tensor version counters do not see); the denoiser modules re-pack their bf16 inference weights when it changes.
+weights_epoch = 0
 
 
 def ptr(t: Optional[torch.Tensor], dtype=None) -> C.c_void_p:

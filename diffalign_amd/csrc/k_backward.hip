@@ -1,0 +1,380 @@
+// Training path (diffusion_abstract.py:134-225 + training/helpers.py:139-142): the pieces of the fp32 training
+// forward / backward that are not plain dense contractions.  The contractions themselves (every nn.Linear, forward and both
+// backward products) are library GEMMs under torch.autograd; these kernels are wrapped as torch.autograd.Functions in
+// diffalign_amd/autograd_ops.py:
+//   k_attn_fwd / k_attn_bwd     the per-pair, per-channel core of NodeEdgeBlock (layers.py:225-265): Y = Q_i K_j / sqrt(df) (E1+1) + E2,
+//                               FiLM by y, softmax over keys per channel without key mask, weighted V
+//   k_ln_bwd                    LayerNorm backward (normX/E/y 1,2, layers.py:341-359)
+//   k_pool_fwd / k_pool_bwd     Xtoy / Etoy pooled statistics [mean, min, max, unbiased std] (layers.py:15-47)
+//   k_vb_grad                   d elbo_batch_quick / d logits (elbo.py:273-334, log-space posterior helpers.py:772-781)
+//   k_adamw                     AdamW with amsgrad, one fused pass over a flat parameter buffer (utils/setup.py:356)
+// Training batches are small (8-16 graphs, n <= 140: align_absorbing.yaml:49-88), so 256-wide per-pair tensors are materialised
+// here in fp32 (321 MB each at B = 16, n = 140), as the reference does; everything is HBM-bound streaming.
+#include "common.h"
+#include <cmath>
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// NodeEdgeBlock core.  One workgroup per query row (b,i), one thread per channel (strided when dx > blockDim).
+// Q, K, V (B,n,dx) already masked; E1 = e_mul(E), E2 = e_add(E) raw linear outputs (B,n,n,dx), masked here by m_i m_j.
+// Z = ye1 + (ye2 + 1) Y is the input of e_out; wV the input of the y_x FiLM; (smax, ssum) the softmax statistics kept for backward.
+__global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                  const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                  const float* __restrict__ ye1, const float* __restrict__ ye2, float qscale,
+                                                  float* __restrict__ Z, float* __restrict__ wV, float* __restrict__ smax,
+                                                  float* __restrict__ ssum, int n, int dx) {
+  const int b = blockIdx.y, i = blockIdx.x;
+  const size_t row = (size_t)b * n + i;
+  const bool mi = nm[row] != 0;
+  for (int c = threadIdx.x; c < dx; c += blockDim.x) {
+    const float q = Q[row * dx + c], f1 = ye1[(size_t)b * dx + c], f2 = ye2[(size_t)b * dx + c] + 1.f;
+    float m = -INFINITY, l = 0.f, a = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const size_t kj = ((size_t)b * n + j) * dx + c, off = (row * n + j) * dx + c;
+      const bool pm = mi && nm[(size_t)b * n + j] != 0;
+      const float e1 = pm ? E1[off] : 0.f, e2 = pm ? E2[off] : 0.f;
+      const float y = (q * K[kj]) * qscale * (e1 + 1.f) + e2;
+      Z[off] = f1 + f2 * y;
+      const float mn = fmaxf(m, y), sc = expf(m - mn), p = expf(y - mn);
+      l = l * sc + p; a = a * sc + p * V[kj]; m = mn;
+    }
+    wV[row * dx + c] = a / l; smax[row * dx + c] = m; ssum[row * dx + c] = l;
+  }
+}
+
+// Backward of the same: inputs dZ (B,n,n,dx), dwV (B,n,dx).  dK, dV (zero-filled by the caller) are summed over query rows with
+// fp32 atomics (the only non-deterministic sums of the training path); dye1, dye2 (B,dx, zero-filled) likewise, once per row.
+__global__ void __launch_bounds__(256) k_attn_bwd(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                  const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                  const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
+                                                  const float* __restrict__ smax, const float* __restrict__ ssum,
+                                                  const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
+                                                  float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dE1,
+                                                  float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
+  const int b = blockIdx.y, i = blockIdx.x;
+  const size_t row = (size_t)b * n + i;
+  const bool mi = nm[row] != 0;
+  for (int c = threadIdx.x; c < dx; c += blockDim.x) {
+    const float q = Q[row * dx + c], f2 = ye2[(size_t)b * dx + c] + 1.f;
+    const float m = smax[row * dx + c], inv_l = 1.f / ssum[row * dx + c];
+    const float g = dwV[row * dx + c], D = g * wV[row * dx + c];          // sum_j attn_j * (dwV V_j)
+    float dq = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const size_t kj = ((size_t)b * n + j) * dx + c, off = (row * n + j) * dx + c;
+      const bool pm = mi && nm[(size_t)b * n + j] != 0;
+      const float k = K[kj], v = V[kj];
+      const float e1 = (pm ? E1[off] : 0.f) + 1.f, e2 = pm ? E2[off] : 0.f;
+      const float qk = (q * k) * qscale;
+      const float y = qk * e1 + e2;
+      const float attn = expf(y - m) * inv_l;
+      const float dz = dZ[off];
+      const float dy = dz * f2 + attn * (g * v - D);
+      d1 += dz; d2 += dz * y;
+      dE2[off] = pm ? dy : 0.f;
+      dE1[off] = pm ? dy * qk : 0.f;
+      const float dqk = dy * e1 * qscale;
+      dq += dqk * k;
+      atomicAdd(dK + kj, dqk * q);
+      atomicAdd(dV + kj, attn * g);
+    }
+    dQ[row * dx + c] = dq;
+    atomicAdd(dye1 + (size_t)b * dx + c, d1);
+    atomicAdd(dye2 + (size_t)b * dx + c, d2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward, eps 1e-5.  s = the normalised input (a + b of the residual), one wave per row, grid-stride over rows;
+// dgamma / dbeta (zero-filled) receive one atomic per lane element per wave.
+template <int D>
+__global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                float* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows) {
+  constexpr int PER = (D + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+  float gm[PER], ag[PER], ab[PER];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; gm[t] = c < D ? gamma[c] : 0.f; ag[t] = 0.f; ab[t] = 0.f; }
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  for (long long r = wave; r < rows; r += nwave) {
+    float x[PER], g[PER];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; x[t] = c < D ? s[r * D + c] : 0.f; g[t] = c < D ? dy[r * D + c] : 0.f; sum += x[t]; }
+    const float mean = wsum(sum) * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; const float d = c < D ? x[t] - mean : 0.f; var += d * d; }
+    const float rstd = rsqrtf(wsum(var) * (1.f / D) + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int c = lane + 64 * t;
+      x[t] = c < D ? (x[t] - mean) * rstd : 0.f;                          // xhat
+      ag[t] += g[t] * x[t]; ab[t] += g[t];
+      g[t] *= gm[t];                                                     // dxhat
+      s1 += g[t]; s2 += g[t] * x[t];
+    }
+    s1 = wsum(s1) * (1.f / D); s2 = wsum(s2) * (1.f / D);
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; if (c < D) ds[r * D + c] = rstd * (g[t] - s1 - x[t] * s2); }
+  }
+#pragma unroll
+  for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; if (c < D) { atomicAdd(dgamma + c, ag[t]); atomicAdd(dbeta + c, ab[t]); } }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Xtoy / Etoy: T (B,N,d) -> z (B,4,d) = [mean, min, max, unbiased std] over the N rows (padding included), arg (B,2,d) = row of the
+// min / max (first occurrence).  Workgroup = (graph, 64 channels), 256 threads = 4 row groups x 64 channels.
+__global__ void __launch_bounds__(256) k_pool_fwd(const float* __restrict__ T, float* __restrict__ z, int* __restrict__ arg, int N, int d) {
+  __shared__ double s_s[4][64], s_q[4][64];
+  __shared__ float s_mn[4][64], s_mx[4][64];
+  __shared__ int s_imn[4][64], s_imx[4][64];
+  const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY; int imn = 0, imx = 0;
+  if (c < d)
+    for (int r = rg; r < N; r += 4) {
+      const float v = T[((size_t)b * N + r) * d + c];
+      s += v; q += (double)v * v;
+      if (v < mn) { mn = v; imn = r; }
+      if (v > mx) { mx = v; imx = r; }
+    }
+  s_s[rg][cl] = s; s_q[rg][cl] = q; s_mn[rg][cl] = mn; s_mx[rg][cl] = mx; s_imn[rg][cl] = imn; s_imx[rg][cl] = imx;
+  __syncthreads();
+  if (rg == 0 && c < d) {
+    for (int g = 1; g < 4; ++g) {
+      s += s_s[g][cl]; q += s_q[g][cl];
+      if (s_mn[g][cl] < mn || (s_mn[g][cl] == mn && s_imn[g][cl] < imn)) { mn = s_mn[g][cl]; imn = s_imn[g][cl]; }
+      if (s_mx[g][cl] > mx || (s_mx[g][cl] == mx && s_imx[g][cl] < imx)) { mx = s_mx[g][cl]; imx = s_imx[g][cl]; }
+    }
+    const double mean = s / N;
+    const double var = N > 1 ? fmax(0.0, (q - s * mean) / (N - 1)) : 0.0;
+    float* o = z + (size_t)b * 4 * d;
+    o[c] = (float)mean; o[d + c] = mn; o[2 * d + c] = mx; o[3 * d + c] = (float)sqrt(var);
+    arg[((size_t)b * 2) * d + c] = imn; arg[((size_t)b * 2 + 1) * d + c] = imx;
+  }
+}
+// dT = dmean / N + dstd (x - mean) / ((N-1) std) + [row == argmin] dmin + [row == argmax] dmax   (std = 0: that term is dropped)
+__global__ void __launch_bounds__(256) k_pool_bwd(const float* __restrict__ T, const float* __restrict__ z, const int* __restrict__ arg,
+                                                  const float* __restrict__ dz, float* __restrict__ dT, int N, int d, long long total) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % d);
+  const long long br = t / d;
+  const int r = (int)(br % N), b = (int)(br / N);
+  const float* zb = z + (size_t)b * 4 * d; const float* gb = dz + (size_t)b * 4 * d;
+  const float mean = zb[c], sd = zb[3 * d + c];
+  float g = gb[c] / N;
+  if (sd > 0.f && N > 1) g += gb[3 * d + c] * (T[t] - mean) / ((float)(N - 1) * sd);
+  if (arg[((size_t)b * 2) * d + c] == r) g += gb[d + c];
+  if (arg[((size_t)b * 2 + 1) * d + c] == r) g += gb[2 * d + c];
+  dT[t] = g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// d elbo_batch_quick / d logits (elbo.py:273-334), avg_over_batch = True.  Per free row of a graph with t > 1 the term is the
+// log-space KL(q || p) of compute_Lt (helpers.py:772-781):  a_k = log(v_k + 1e-30) + log(u_k + 1e-30), u = softmax(logits) Qbar_{t-1},
+// v = z_t Q_t^T, logp = a - logsumexp(a);  dKL/da = softmax(a) - q;  dKL/ds_j = sum_k (P_k - q_k) Qsb[j][k] / (u_k + 1e-30);
+// dKL/dlogit_i = s_i (g_i - sum_j s_j g_j).  Rows of graphs with t == 1 carry -log p(x_0): gradient softmax - onehot.  Weight w =
+// weight / #free rows of the batch.  Not-free rows: zero.
+template <int K, bool IS_E>
+__global__ void __launch_bounds__(256) k_vb_grad(const float* __restrict__ tr, const float* __restrict__ zt, const float* __restrict__ lg,
+                                                 const float* __restrict__ Qt, const float* __restrict__ Qsb, const uint8_t* __restrict__ t_is_1,
+                                                 const uint8_t* __restrict__ fm, const float* __restrict__ sums, float scale,
+                                                 float* __restrict__ grad, int B, int n) {
+  __shared__ float sQ[2 * K * K];
+  __shared__ float s_w;
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < K * K; t += blockDim.x) { sQ[t] = Qt[(size_t)b * K * K + t]; sQ[K * K + t] = Qsb[(size_t)b * K * K + t]; }
+  if (threadIdx.x == 0) {
+    double cnt = 0.0;
+    for (int g = 0; g < B; ++g) cnt += sums[g * 4 + (IS_E ? 3 : 1)];
+    s_w = cnt > 0.0 ? (float)((double)scale / cnt) : 0.f;
+  }
+  __syncthreads();
+  const float w = s_w;
+  const int M = IS_E ? n * n : n;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const bool free_ = IS_E ? (fm[b * n + p / n] != 0 && fm[b * n + p % n] != 0) : fm[b * n + p] != 0;
+  const size_t r = ((size_t)b * M + p) * K;
+  if (!free_) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) grad[r + k] = 0.f;
+    return;
+  }
+  float s[K];
+  float mx = -INFINITY;
+  int x0 = 0, xt = 0; float b0 = tr[r], bt = zt[r];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    s[k] = lg[r + k]; mx = fmaxf(mx, s[k]);
+    const float t0 = tr[r + k], t1 = zt[r + k];
+    if (t0 > b0) { b0 = t0; x0 = k; }
+    if (t1 > bt) { bt = t1; xt = k; }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { s[k] = expf(s[k] - mx); sum += s[k]; }
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] /= sum;
+  if (t_is_1[b]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) grad[r + k] = w * (s[k] - (k == x0 ? 1.f : 0.f));
+    return;
+  }
+  const float* Qa = sQ; const float* Qb = sQ + K * K;
+  float q[K], a[K], u[K];
+  float sq = 0.f, am = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float v = Qa[k * K + xt];
+    q[k] = v * Qb[x0 * K + k]; sq += q[k];
+    float bp = 0.f;
+    for (int j = 0; j < K; ++j) bp += s[j] * Qb[j * K + k];
+    u[k] = bp + 1e-30f;
+    a[k] = logf(v + 1e-30f) + logf(u[k]);
+    am = fmaxf(am, a[k]);
+  }
+  float sa = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - am); sa += a[k]; }
+#pragma unroll
+  for (int k = 0; k < K; ++k) a[k] = (a[k] / sa - q[k] / sq) / u[k];                    // (P_k - q_k) / u_k
+  float g[K];
+  float sg = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    float t = 0.f;
+    for (int k = 0; k < K; ++k) t += a[k] * Qb[j * K + k];
+    g[j] = t; sg += s[j] * t;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) grad[r + k] = w * s[k] * (g[k] - sg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// AdamW(amsgrad) on a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay, bias corrections by step).
+__global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                               float* __restrict__ vmax, long long N, float lr, float b1, float b2, float eps, float wd,
+                                               float bc1, float bc2_sqrt, float grad_scale) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const float gr = g[t] * grad_scale;
+  float x = p[t];
+  x *= 1.f - lr * wd;
+  const float mm = b1 * m[t] + (1.f - b1) * gr, vv = b2 * v[t] + (1.f - b2) * gr * gr;
+  m[t] = mm; v[t] = vv;
+  float den;
+  if (vmax) { const float vm = fmaxf(vmax[t], vv); vmax[t] = vm; den = sqrtf(vm) / bc2_sqrt + eps; }
+  else den = sqrtf(vv) / bc2_sqrt + eps;
+  p[t] = x - (lr / bc1) * mm / den;
+}
+
+static inline unsigned grid_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+template <int K, bool IS_E>
+static void launch_vb(const float* tr, const float* zt, const float* lg, const float* Qt, const float* Qsb, const uint8_t* t1, const uint8_t* fm,
+                      const float* sums, float scale, float* grad, int B, int n, hipStream_t s) {
+  const int M = IS_E ? n * n : n;
+  k_vb_grad<K, IS_E><<<dim3((M + 255) / 256, B), 256, 0, s>>>(tr, zt, lg, Qt, Qsb, t1, fm, sums, scale, grad, B, n);
+}
+#define VB_DISPATCH(K_, IS_E_, ...)                                                                            \
+  switch (K_) {                                                                                                \
+    case 4: launch_vb<4, IS_E_>(__VA_ARGS__); break;   case 5: launch_vb<5, IS_E_>(__VA_ARGS__); break;         \
+    case 7: launch_vb<7, IS_E_>(__VA_ARGS__); break;   case 29: launch_vb<29, IS_E_>(__VA_ARGS__); break;       \
+    default: da_set_error("unsupported class count %d (built for 4,5,7,29)", K_); return DA_ERR_UNSUPPORTED;   \
+  }
+
+extern "C" {
+
+int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
+                     const float* ye1, const float* ye2, float qscale, float* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
+                     void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0 && dx >= 1, "da_attn_core_fwd: sizes");
+  if (B == 0 || n == 0) return DA_OK;
+  k_attn_fwd<<<dim3(n, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, (hipStream_t)stream>>>(Q, K, V, E1, E2, node_mask, ye1, ye2, qscale, Z, wV,
+                                                                                         smax, ssum, n, dx);
+  DA_CHECK_LAUNCH("da_attn_core_fwd");
+  return DA_OK;
+}
+
+int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
+                     const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const float* dZ, const float* dwV,
+                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, int B, int n, int dx, void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0 && dx >= 1, "da_attn_core_bwd: sizes");
+  if (B == 0 || n == 0) return DA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nb = sizeof(float) * (size_t)B * n * dx, yb = sizeof(float) * (size_t)B * dx;
+  if (hipMemsetAsync(dK, 0, nb, s) != hipSuccess || hipMemsetAsync(dV, 0, nb, s) != hipSuccess || hipMemsetAsync(dye1, 0, yb, s) != hipSuccess ||
+      hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) { da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP; }
+  k_attn_bwd<<<dim3(n, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV,
+                                                                       dE1, dE2, dye1, dye2, n, dx);
+  DA_CHECK_LAUNCH("da_attn_core_bwd");
+  return DA_OK;
+}
+
+int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, long long rows, int D,
+                     void* stream) {
+  DA_CHECK_ARG(rows >= 0, "da_layernorm_bwd: rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * D, st) != hipSuccess) {
+    da_set_error("da_layernorm_bwd: memset failed"); return DA_ERR_HIP;
+  }
+  if (rows == 0) return DA_OK;
+  long long g = (rows + 3) / 4; if (g > 2048) g = 2048;
+  switch (D) {
+    case 32: k_ln_bwd<32><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
+    case 64: k_ln_bwd<64><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
+    case 128: k_ln_bwd<128><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
+    case 256: k_ln_bwd<256><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
+    default: da_set_error("da_layernorm_bwd: width %d not built (32, 64, 128, 256)", D); return DA_ERR_UNSUPPORTED;
+  }
+  DA_CHECK_LAUNCH("da_layernorm_bwd");
+  return DA_OK;
+}
+
+int da_pool_stats_fwd(const float* T, float* z, int* arg, int B, int N, int d, void* stream) {
+  DA_CHECK_ARG(B >= 0 && N >= 1 && d >= 1, "da_pool_stats_fwd: sizes");
+  if (B == 0) return DA_OK;
+  k_pool_fwd<<<dim3((d + 63) / 64, B), 256, 0, (hipStream_t)stream>>>(T, z, arg, N, d);
+  DA_CHECK_LAUNCH("da_pool_stats_fwd");
+  return DA_OK;
+}
+int da_pool_stats_bwd(const float* T, const float* z, const int* arg, const float* dz, float* dT, int B, int N, int d, void* stream) {
+  DA_CHECK_ARG(B >= 0 && N >= 1 && d >= 1, "da_pool_stats_bwd: sizes");
+  if (B == 0) return DA_OK;
+  const long long total = (long long)B * N * d;
+  k_pool_bwd<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(T, z, arg, dz, dT, N, d, total);
+  DA_CHECK_LAUNCH("da_pool_stats_bwd");
+  return DA_OK;
+}
+
+int da_vb_grad(const float* true_X, const float* true_E, const float* zt_X, const float* zt_E, const float* logits_X, const float* logits_E,
+               const float* Qt_x, const float* Qsb_x, const float* Qt_e, const float* Qsb_e, const uint8_t* t_is_1, const uint8_t* mask_x,
+               const uint8_t* mask_e, const float* sums, float weight_X, float weight_E, float* grad_X, float* grad_E, int B, int n, int kx,
+               int ke, void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0 && sums && mask_x && mask_e && t_is_1, "da_vb_grad: arguments");
+  if (B == 0 || n == 0) return DA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (grad_X) { VB_DISPATCH(kx, false, true_X, zt_X, logits_X, Qt_x, Qsb_x, t_is_1, mask_x, sums, weight_X, grad_X, B, n, s) }
+  if (grad_E) { VB_DISPATCH(ke, true, true_E, zt_E, logits_E, Qt_e, Qsb_e, t_is_1, mask_e, sums, weight_E, grad_E, B, n, s) }
+  DA_CHECK_LAUNCH("da_vb_grad");
+  return DA_OK;
+}
+
+int da_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  DA_CHECK_ARG(N >= 0 && step >= 1 && param && grad && exp_avg && exp_avg_sq, "da_adamw: arguments");
+  if (N == 0) return DA_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  k_adamw<<<grid_for(N, 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, N, lr, beta1, beta2, eps, weight_decay,
+                                                          bc1, bc2, grad_scale);
+  DA_CHECK_LAUNCH("da_adamw");
+  return DA_OK;
+}
+
+}  // extern "C"

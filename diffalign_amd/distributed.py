@@ -118,6 +118,17 @@ def sample_conditions_sharded(conditions, n_samples: int, sample_for_condition: 
     return sample_sharded(len(conditions), n_samples, n_max, run, group=group, dst=dst, device=device)
 
 
+def allreduce_flat_gradient(flat_grad: torch.Tensor, group=None) -> int:
+    """Data-parallel training (BASELINE configs[3]): SUM all-reduce of the flat fp32 gradient buffer of optim.FlatAdamW -- the whole
+    32.7 MB align_absorbing gradient as ONE ring all-reduce (xGMI is per-link bound: few large transfers) -- in place; returns the
+    world size (the optimiser divides by it: da_adamw's grad_scale).  Parameters the objective never reaches (mlp_out_y,
+    self_attn.y_y, skip_scaling_3) keep zero entries on every rank, so no unused-parameter handling is needed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 1
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return dist.get_world_size(group)
+
+
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
     """Data-parallel training: average the ranks' gradients in place and return them.  The tensors are packed
     in sorted-name order into flat fp32 buckets of <= bucket_bytes (the whole align_absorbing gradient is 32.7 MB: one or

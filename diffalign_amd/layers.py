@@ -1,6 +1,6 @@
 """nn.Module shells with the reference's class names, constructor signatures and state-dict keys
-(diffalign/neuralnet/layers.py).  They only HOLD parameters; forward runs in the HIP library (engine.py).
-Inference only in this round: calling them with autograd enabled on parameters raises."""
+(diffalign/neuralnet/layers.py).  They only HOLD parameters; the inference forward runs in the HIP library (engine.py), the training forward in
+train_forward.py (which calls the nn.Linear members as the library GEMMs they are)."""
 from __future__ import annotations
 
 import torch

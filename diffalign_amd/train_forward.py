@@ -1,0 +1,80 @@
+"""fp32 training forward of the denoiser under torch.autograd.
+
+Same arithmetic as GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713) and
+XEyTransformerLayer / NodeEdgeBlock (neuralnet/layers.py:204-361) in train mode, laid out for a backward pass:
+  * every nn.Linear is called as the torch module it is (library GEMM; autograd supplies both backward products);
+  * the per-pair attention core, the LayerNorms, the pooled statistics and the hidden-feature mask are HIP autograd.Functions
+    (diffalign_amd/autograd_ops.py);
+  * masks, residual adds, ReLU, dropout, the symmetrisation and the product->reactant skip gather are torch elementwise glue.
+The fused bf16 inference path (engine.model_forward) is not differentiable; training batches are small (8-16 graphs, n <= 140),
+so this path materialises the 256-wide per-pair tensors in fp32 like the reference does (which runs it under fp16 autocast).
+Parameters without a gradient in the reference (mlp_out_y, self_attn.y_y, skip_scaling_3: transformer_model_with_y.py:673-681,
+layers.py:277-280) get none here either."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .autograd_ops import AttnCore, AddLayerNorm, PoolStats, MaskDense, qscale_of
+
+
+def _node_edge_block(a, X, E, y, nm_u8, xm, em):
+    """layers.py:204-284."""
+    Q, K, V = a.q(X) * xm, a.k(X) * xm, a.v(X) * xm
+    Z, wV = AttnCore.apply(Q, K, V, a.e_mul(E), a.e_add(E), nm_u8, a.y_e_add(y), a.y_e_mul(y), qscale_of(a.dx, a.n_head))
+    newE = a.e_out(Z) * em
+    newX = a.x_out(a.y_x_add(y)[:, None, :] + (a.y_x_mul(y)[:, None, :] + 1) * wV) * xm
+    new_y = a.y_out(y + a.x_y.lin(PoolStats.apply(X)) + a.e_y.lin(PoolStats.apply(E)))
+    return newX, newE, new_y
+
+
+def _layer(layer, X, E, y, nm_u8, xm, em, training):
+    """layers.py:330-361 (post-LN residual blocks; dropout only in train mode)."""
+    drop = (lambda t: F.dropout(t, layer.dropout_p, True)) if training and layer.dropout_p > 0 else (lambda t: t)
+    nX, nE, ny = _node_edge_block(layer.self_attn, X, E, y, nm_u8, xm, em)
+    X = AddLayerNorm.apply(X, drop(nX), layer.normX1.weight, layer.normX1.bias)
+    E = AddLayerNorm.apply(E, drop(nE), layer.normE1.weight, layer.normE1.bias)
+    y = AddLayerNorm.apply(y, drop(ny), layer.norm_y1.weight, layer.norm_y1.bias)
+    X = AddLayerNorm.apply(X, drop(layer.linX2(drop(F.relu(layer.linX1(X))))), layer.normX2.weight, layer.normX2.bias)
+    E = AddLayerNorm.apply(E, drop(layer.linE2(drop(F.relu(layer.linE1(E))))), layer.normE2.weight, layer.normE2.bias)
+    y = AddLayerNorm.apply(y, drop(layer.lin_y2(drop(F.relu(layer.lin_y1(y))))), layer.norm_y2.weight, layer.norm_y2.bias)
+    return X, E, y
+
+
+def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None):
+    """Differentiable forward of the denoiser module `m`; returns (X logits, E logits, y) like the module's forward."""
+    if not X.is_cuda:
+        raise L.DiffAlignHipError('denoiser inputs must be on a HIP device (no CPU fallback)')
+    X, E, y = X.float(), E.float(), y.float()
+    B, n = X.shape[:2]
+    nm_u8 = L.as_u8(node_mask)
+    xm = node_mask[:, :, None].float()
+    em = xm[:, :, None, :] * xm[:, None, :, :]
+    Xh, Eh, yh = m.mlp_in_X(X), m.mlp_in_E(E), m.mlp_in_y(y)
+    Eh = (Eh + Eh.transpose(1, 2)) / 2
+    Xh, Eh = MaskDense.apply(Xh, Eh, nm_u8)
+    if pos_encodings is not None:
+        Xh = Xh + pos_encodings.float()
+    for layer in m.tf_layers:
+        Xh, Eh, yh = _layer(layer, Xh, Eh, yh, nm_u8, xm, em, m.training)
+    kx, ke, ky = m.out_dim_X, m.out_dim_E, m.out_dim_y
+    Xo = m.mlp_out_X(Xh) + X[..., :kx]
+    Eo = (m.mlp_out_E(Eh) + E[..., :ke]) * (~torch.eye(n, dtype=torch.bool, device=X.device))[None, :, :, None]
+    Eo = 0.5 * (Eo + Eo.transpose(1, 2))
+    yo = yh[..., :ky] + y[..., :ky]
+    if getattr(m, 'p_to_r_skip_connection', False):
+        # transformer_model_with_y.py:686-704 (alignment 'correct') as a gather: mapped reactant-side nodes / pairs take s1 times the
+        # product's input features, every other pair s2 on class 0
+        src = torch.empty(B, n, dtype=torch.int32, device=X.device)
+        L.check(L.lib().da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
+                                       L.ptr(src), B, n, L.stream()), 'da_align_index')
+        sel = src >= 0
+        idx = src.clamp_min(0).long()
+        Xo = Xo + m.skip_scaling * torch.gather(X[..., :kx], 1, idx[:, :, None].expand(-1, -1, kx)) * sel[:, :, None]
+        pair = (sel[:, :, None] & sel[:, None, :])[..., None]
+        bi = torch.arange(B, device=X.device)[:, None, None]
+        Eg = E[bi, idx[:, :, None], idx[:, None, :]][..., :ke]
+        first = torch.zeros(ke, device=X.device); first[0] = 1.0
+        Eo = Eo + m.skip_scaling * Eg * pair + m.skip_scaling_2 * first * (~pair)
+    return Xo, Eo, yo

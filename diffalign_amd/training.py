@@ -1,11 +1,12 @@
-"""Training step (diffalign/diffusion/diffusion_abstract.py:134-225) -- the part that is built.
+"""Training step (diffalign/diffusion/diffusion_abstract.py:134-225, training/helpers.py:139-142).
 
-Built: the forward of `training_step` through the HIP path (apply_noise, apply_mask, denoiser, the 'ce' / 'vb' / 'vbce'
-loss values) and the FIRST stage of the backward for the 'ce' loss: d loss / d logits (da_ce_grad) and, from it, the
-gradients of the output stage's last parameters (mlp_out_X.2, skip_scaling, skip_scaling_2).  Both are pinned to the
-reference: the loss values and the gradient norms `loss.backward()` leaves on those parameters are golden vectors
-(tests/golden/chain_elbo_tiny.npz).  NOT built: the backward through the transformer layers -- so there
-is no optimizer step yet and `training_backward_output_stage` says so in its name.
+`model.train()` + autograd on: `training_step` runs apply_noise -> apply_mask -> the differentiable fp32 denoiser forward
+(train_forward.py) -> the objective ('ce' / 'vb' / 'vbce') as an autograd.Function, and returns a loss that `backward()`s into
+every parameter; `optim.FlatAdamW` (fused AdamW with amsgrad over one flat buffer) and `distributed.allreduce_flat_gradient`
+complete the step (`train_one_step`).  Loss values and gradient norms are pinned to the reference's own `loss.backward()`
+(tests/golden/chain_elbo_tiny.npz), every parameter's gradient to autograd on the oracle.
+`model.eval()` or no_grad: the same call evaluates the loss VALUES through the fused bf16 inference path (no graph), and
+`training_backward_output_stage` gives the hand-derived last-stage gradients of round 1.
 """
 from __future__ import annotations
 
@@ -60,6 +61,21 @@ class TrainingMixin:
         z_keep = z_t.get_new_object()                                                                         # :144
         if not d.diffuse_edges: z_t.E = dense_data.E.clone()
         if not d.diffuse_nodes: z_t.X = dense_data.X.clone()
+        loss_kind = getattr(getattr(self.cfg, 'train', None), 'loss', 'ce')
+        if self.model.training and torch.is_grad_enabled():
+            # the differentiable path: fp32 training forward under autograd (train_forward.py), the objective as one
+            # autograd.Function whose backward is da_ce_grad / da_vb_grad; `loss.backward()` then fills every parameter's .grad
+            from .autograd_ops import DiffusionLoss
+            pred = self.forward(z_t=z_t)
+            loss = DiffusionLoss.apply(pred.X, pred.E, self, dense_data, z_keep, node_masks, loss_kind)
+            self._train_ctx = None
+            loss_X = loss_E = torch.zeros((1,))
+            if loss_kind == 'ce':
+                with torch.no_grad():
+                    rX, rE = E_.elbo_rows(E_.LOGP, dense_data, logits=pred.get_new_object(X=pred.X.detach(), E=pred.E.detach()))
+                    mx, me = node_masks[0].bool(), node_masks[1].bool()
+                    loss_X, loss_E = -rX[mx], -rE[me[:, :, None] & me[:, None, :]]
+            return loss_X, loss_E, loss
         saved: Dict[str, torch.Tensor] = {}
         self.model._saved = saved
         try:
@@ -68,7 +84,6 @@ class TrainingMixin:
         finally:
             self.model._saved = None
         lam = d.lambda_train[0]
-        loss_kind = getattr(getattr(self.cfg, 'train', None), 'loss', 'ce')
         loss_X = loss_E = torch.zeros((1,))
         if loss_kind in ('ce', 'vbce'):
             rX, rE = E_.elbo_rows(E_.LOGP, dense_data, logits=pred)
@@ -86,6 +101,18 @@ class TrainingMixin:
             raise ValueError(f'Unknown loss {loss_kind}')
         self._train_ctx = dict(pred=pred, data=dense_data, node_masks=node_masks, saved=saved, loss_kind=loss_kind, lam=lam)
         return loss_X, loss_E, loss
+
+    def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None):
+        """training/helpers.py:130-142 for one batch: zero_grad, training_step, backward, gradient all-reduce over `group` (data
+        parallel: one process per GPU, RCCL), fused AdamW step.  Returns the (detached) loss."""
+        from . import distributed
+        assert self.model.training, 'call model.train() first'
+        optimizer.zero_grad()
+        _, _, loss = self.training_step(data, i, t_int=t_int, noise=noise, z_t=z_t)
+        loss.backward()
+        world = distributed.allreduce_flat_gradient(optimizer.flat_grad, group=group)
+        optimizer.step(grad_scale=1.0 / world)
+        return loss.detach()
 
     def training_backward_output_stage(self) -> Dict[str, torch.Tensor]:
         """First stage of `loss.backward()` for train.loss == 'ce': gradients with respect to the logits and to the output

@@ -1,7 +1,8 @@
 """Denoiser modules with the reference's nn.Module contract (diffalign/neuralnet/transformer_model_with_y.py:
 GraphTransformerWithY :33-112, GraphTransformerWithYAtomMapPosEmb :557-714): same constructor arguments, same
 state-dict keys/shapes, same forward signature and 4-tuple result.  forward() runs in libdiffalign_hip.so
-(bf16 MFMA, fp32 accumulate) -- no eager fallback."""
+(bf16 MFMA, fp32 accumulate) -- no eager fallback.  In train() mode with autograd enabled the modules run the differentiable
+fp32 training forward of train_forward.py instead (HIP autograd.Functions + library GEMMs)."""
 from __future__ import annotations
 
 import torch
@@ -36,17 +37,18 @@ class _DenoiserBase(nn.Module):
         self._saved = None      # dict filled by engine.model_forward for the output-stage backward (training.py)
 
     def _pack(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (str(device), L.weights_epoch) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is None or self._packed_key != key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._packed = engine.PackedModel(sd, device, self.n_layers, self.n_head)
             self._packed_key = key
         return self._packed
 
+    def _differentiable(self):
+        """train() mode with autograd on: the fp32 training forward (train_forward.py) instead of the fused bf16 inference path."""
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def _check(self, X):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError('diffalign_amd: the HIP denoiser is forward-only in this round (training/backward '
-                                      'is SURVEY §8 config 4, not built yet); call under torch.no_grad() / .eval()')
         if not X.is_cuda:
             raise L.DiffAlignHipError('denoiser inputs must be on a HIP device (no CPU fallback)')
 
@@ -59,6 +61,9 @@ class GraphTransformerWithY(_DenoiserBase):
 
     def forward(self, X, E, y, node_mask):
         self._check(X)
+        if self._differentiable():
+            from .train_forward import forward_train
+            return forward_train(self, X, E, y, node_mask) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, save=self._saved)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
@@ -87,6 +92,9 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
     def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments):
         assert atom_map_numbers is not None
         self._check(X)
+        if self._differentiable():
+            from .train_forward import forward_train
+            return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
                                           use_skip=self.p_to_r_skip_connection, save=self._saved)

@@ -131,6 +131,43 @@ int da_ce_grad(const float* true_X, const float* true_E, const float* logits_X, 
 int da_skip_grad(const float* grad_X, const float* grad_E, const float* X_in, int dx_in, const float* E_in, int de_in, const int* src,
                  float* out, int B, int n, int kx, int ke, void* stream);
 
+/* ---- training path: the non-GEMM pieces of the fp32 forward / backward (diffusion_abstract.py:134-225, training/helpers.py:139-142).
+ * Every nn.Linear of the training forward and both of its backward products are library GEMMs under torch.autograd; these entry
+ * points are the bodies of the torch.autograd.Functions of diffalign_amd/autograd_ops.py.  All tensors fp32. ---- */
+
+/* Core of NodeEdgeBlock.forward (layers.py:225-265) per pair and channel: Y = Q_i K_j qscale (E1 m_i m_j + 1) + E2 m_i m_j,
+ * Z = ye1 + (ye2 + 1) Y (the input of e_out), attn = softmax over keys j per channel (no key mask), wV = sum_j attn V_j.
+ * Q, K, V (B,n,dx) masked; E1 = e_mul(E), E2 = e_add(E) (B,n,n,dx) unmasked; ye1 = y_e_add(y), ye2 = y_e_mul(y) (B,dx).
+ * smax / ssum (B,n,dx): the softmax statistics the backward reuses. */
+int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
+                     const float* ye1, const float* ye2, float qscale, float* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
+                     void* stream);
+/* Its backward: from dZ (B,n,n,dx) and dwV (B,n,dx) to dQ, dK, dV (B,n,dx), dE1, dE2 (B,n,n,dx; zero on masked pairs), dye1, dye2
+ * (B,dx).  dK, dV, dye1, dye2 are cleared here and summed with fp32 atomics (order-dependent in the last bits). */
+int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
+                     const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const float* dZ, const float* dwV,
+                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, int B, int n, int dx, void* stream);
+/* LayerNorm backward (eps 1e-5; layers.py:341-359): s (rows,D) = the normalised input, dy the gradient of gamma * xhat + beta ->
+ * ds (rows,D), dgamma (D), dbeta (D).  D in {32, 64, 128, 256}. */
+int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, long long rows, int D,
+                     void* stream);
+/* Xtoy / Etoy pooled statistics (layers.py:15-47) of T (B,N,d): z (B,4,d) = [mean, min, max, unbiased std] over the N rows, arg
+ * (B,2,d) int32 = row index of the min / max (first occurrence); and the backward dT from dz. */
+int da_pool_stats_fwd(const float* T, float* z, int* arg, int B, int N, int d, void* stream);
+int da_pool_stats_bwd(const float* T, const float* z, const int* arg, const float* dz, float* dT, int B, int N, int d, void* stream);
+/* d elbo_batch_quick / d logits (elbo.py:273-334, avg_over_batch=True): free rows of graphs with t > 1 carry the log-space
+ * KL(q(z_s|z_t,x_0) || p(z_s|z_t)) of compute_Lt (helpers.py:772-781), graphs with t == 1 (t_is_1[b] != 0) carry -log p(x_0).
+ * Qt = Q_t, Qsb = Qbar_{t-1} per graph (B,K,K); sums = da_masked_sums' output (its counts); weight_X = diffusion_steps *
+ * diffuse_nodes, weight_E = diffusion_steps * lambda_E * diffuse_edges. */
+int da_vb_grad(const float* true_X, const float* true_E, const float* zt_X, const float* zt_E, const float* logits_X, const float* logits_E,
+               const float* Qt_x, const float* Qsb_x, const float* Qt_e, const float* Qsb_e, const uint8_t* t_is_1, const uint8_t* mask_x,
+               const uint8_t* mask_e, const float* sums, float weight_X, float weight_E, float* grad_X, float* grad_E, int B, int n, int kx,
+               int ke, void* stream);
+/* One AdamW step (torch.optim.AdamW semantics, decoupled weight decay; amsgrad when max_exp_avg_sq != NULL: utils/setup.py:356) on
+ * a flat buffer of N parameters; grad is multiplied by grad_scale first (1 / world size, or the inverse loss scale). */
+int da_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 /* ---- L2 denoiser (graph transformer) -------------------------------------------------------------------------------
  * Hidden edge features travel between these calls as bf16 (B,n,n,de); node features X and globals y stay fp32.
  * Weights arrive pre-packed by diffalign_amd/pack.py: "blob" = MFMA fragments (1 KiB each, lane-linear, bf16) followed

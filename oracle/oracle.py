@@ -377,8 +377,8 @@ def align_index(atom_map_numbers: Tensor, mol_assignments: Tensor) -> Tensor:
     return src
 
 
-def p_to_r_skip(X_o, E_o, X_in, E_in, src: Tensor, s1: float, s2: float, Kx: int, Ke: int):
-    """transformer_model_with_y.py:686-701."""
+def p_to_r_skip(X_o, E_o, X_in, E_in, src: Tensor, s1, s2, Kx: int, Ke: int):
+    """transformer_model_with_y.py:686-701.  s1, s2: floats or the (1,) parameters themselves (then differentiable in them)."""
     X_o = X_o.clone(); E_o = E_o.clone()
     B, n = src.shape
     for b in range(B):
@@ -418,8 +418,7 @@ def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n
     Eo = 0.5 * (Eo + Eo.transpose(1, 2))
     if p_to_r_skip_connection:
         src = align_index(atom_map_numbers, mol_assignments)
-        Xo, Eo = p_to_r_skip(Xo, Eo, X_in, E_in, src, float(sd[prefix + 'skip_scaling']),
-                             float(sd[prefix + 'skip_scaling_2']), Kx, Ke)
+        Xo, Eo = p_to_r_skip(Xo, Eo, X_in, E_in, src, sd[prefix + 'skip_scaling'], sd[prefix + 'skip_scaling_2'], Kx, Ke)
     return Xo, Eo, yo
 
 
@@ -530,6 +529,20 @@ def ce_loss(logits_X, logits_E, true_X, true_E, mask_x, mask_e, lambda_E: float)
 # --------------------------------------------------------------------------------------
 # a16 full reverse-diffusion chain (diffusion/sampling.py:11-197) with explicit noise
 # --------------------------------------------------------------------------------------
+def elbo_batch_quick(true_X, true_E, zt_X, zt_E, logits_X, logits_E, tabs, t_vec: Tensor, T: int, mask_x, mask_e,
+                     lambda_E: float, diffuse_nodes=True, diffuse_edges=True):
+    """diffusion/elbo.py:273-334 (avg_over_batch=True): the single-timestep ELBO estimator the 'vb' / 'vbce' training losses
+    use -- log-space L_t rows, replaced by the reconstruction term on graphs with t == 1, masked mean, times T, plus the prior KL."""
+    LtX, LtE = compute_Lt(true_X, true_E, zt_X, zt_E, logits_X, logits_E, tabs, t_vec, mask_x, mask_e, log_space=True)
+    kpX, kpE = kl_prior(true_X, true_E, tabs, T, mask_x, mask_e)
+    r1X, r1E = reconstruction_logp(true_X, true_E, F.log_softmax(logits_X, -1), F.log_softmax(logits_E, -1), mask_x, mask_e)
+    is1 = (t_vec.long() == 1)
+    tX = torch.where(is1[:, None], -r1X, LtX)
+    tE = torch.where(is1[:, None, None], -r1E, LtE) * lambda_E
+    kw = dict(avg_over_batch=True, diffuse_nodes=diffuse_nodes, diffuse_edges=diffuse_edges)
+    return mean_without_masked(tX, tE, mask_x, mask_e, **kw) * T + mean_without_masked(kpX, kpE * lambda_E, mask_x, mask_e, **kw)
+
+
 def fix_masks(B: int, n: int, node_idx, edge_idx) -> Tuple[Tensor, Tensor]:
     """utils/graph.py:621-656 fix_nodes_and_edges_by_idx: (B,n) / (B,n,n) bool masks from per-graph index lists."""
     mX = torch.zeros(B, n, dtype=torch.bool); mE = torch.zeros(B, n, n, dtype=torch.bool)

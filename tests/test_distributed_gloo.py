@@ -151,3 +151,44 @@ def test_two_rank_gradient_allreduce_is_the_mean(tmp_path):
     res = torch.load(out)
     for k in per_rank[0]:
         assert torch.allclose(res[k], (per_rank[0][k] + per_rank[1][k]) / 2, rtol=1e-6, atol=1e-7), k
+
+
+def _flat_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from diffalign_amd.distributed import allreduce_flat_gradient
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 3))      # same weights on every rank
+    data = torch.Generator().manual_seed(300)
+    x, y = torch.randn(8, 6, generator=data), torch.randn(8, 3, generator=data)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]                                  # this rank's half of the batch
+    flat = torch.zeros(sum(p.numel() for p in net.parameters()))
+    o = 0
+    for p in net.parameters():                                                                       # optim.FlatAdamW's layout
+        p.grad = flat[o:o + p.numel()].view_as(p); o += p.numel()
+    ((net(xs) - ys) ** 2).mean().backward()
+    w = allreduce_flat_gradient(flat)
+    assert w == world
+    if rank == 0:
+        torch.save(flat / w, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_equals_the_whole_batch_gradient(tmp_path):
+    """The data-parallel training step (TrainingMixin.train_one_step): SUM all-reduce of the flat gradient buffer, divided by the
+    world size inside the optimiser, == the gradient of the mean loss over the concatenated batch (equal shards)."""
+    from diffalign_amd.distributed import allreduce_flat_gradient
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 3))
+    data = torch.Generator().manual_seed(300)
+    x, y = torch.randn(8, 6, generator=data), torch.randn(8, 3, generator=data)
+    ((net(x) - y) ** 2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert allreduce_flat_gradient(want.clone()) == 1                                                # no process group: world 1, untouched
+    out = str(tmp_path / 'f.pt')
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)

@@ -1,0 +1,246 @@
+"""GPU: the training backward -- every HIP autograd.Function against torch autograd of the same formula, the
+whole denoiser's parameter gradients against autograd through the oracle (which tests/test_oracle_golden.py pins to the
+gradient norms the reference's own `loss.backward()` produced), the fused AdamW against torch.optim.AdamW(amsgrad=True), and a
+few optimisation steps end to end.
+
+Tolerances (fp32 everywhere; sums over up to n*n rows are ordered differently from torch's): per-Function gradients 2e-5
+relative to the largest entry; whole-model parameter gradients 1e-4 of each parameter's gradient norm (measured: 9e-6 worst);
+loss values 2e-5 relative and gradient norms 5e-4 relative against the reference's recorded ones; AdamW 1e-6 absolute after 6 steps."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+from tests.golden.common import weights_of, ATOMS, BONDS
+from tests.test_gpu_elbo import setup, T, KX, KE, D
+from tests.test_oracle_golden import oracle_training_loss, GNORM_PARAMS, _tiny_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def ragged_mask(B, n, g):
+    lens = torch.randint(n // 2, n + 1, (B,), generator=g)
+    lens[0] = n
+    return torch.arange(n)[None, :] < lens[:, None]
+
+
+@pytest.mark.parametrize('B,n,dx,heads', [(3, 20, 64, 4), (2, 37, 256, 8)])
+def test_attention_core_forward_and_backward(B, n, dx, heads):
+    from diffalign_amd.autograd_ops import AttnCore, qscale_of
+    from diffalign_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    nm = ragged_mask(B, n, g)
+    xm = nm[:, :, None].float()
+    mk = lambda *s: torch.randn(*s, generator=g).requires_grad_()
+    Q, K, V, E1, E2, ye1, ye2 = mk(B, n, dx), mk(B, n, dx), mk(B, n, dx), mk(B, n, n, dx), mk(B, n, n, dx), mk(B, dx), mk(B, dx)
+    # layers.py:225-265 restated with torch ops (oracle.node_edge_block without the projections)
+    em = xm[:, :, None, :] * xm[:, None, :, :]
+    Qm, Km, Vm = Q * xm, K * xm, V * xm
+    Y = Qm[:, :, None, :] * Km[:, None, :, :] / math.sqrt(dx // heads) * (E1 * em + 1) + E2 * em
+    Z_ref = ye1[:, None, None, :] + (ye2[:, None, None, :] + 1) * Y
+    wV_ref = (F.softmax(Y, dim=2) * Vm[:, None, :, :]).sum(2)
+    gz, gw = torch.randn(B, n, n, dx, generator=g), torch.randn(B, n, dx, generator=g)
+    ((Z_ref * gz).sum() + (wV_ref * gw).sum()).backward()
+    want = [t.grad.clone() for t in (Q, K, V, E1, E2, ye1, ye2)]
+    dev = [t.detach().to(D).requires_grad_() for t in (Q, K, V, E1, E2, ye1, ye2)]
+    xmd = xm.to(D)
+    Z, wV = AttnCore.apply(dev[0] * xmd, dev[1] * xmd, dev[2] * xmd, dev[3], dev[4], L.as_u8(nm.to(D)), dev[5], dev[6], qscale_of(dx, heads))
+    assert rel(Z, Z_ref) <= 1e-5 and rel(wV, wV_ref) <= 1e-5
+    ((Z * gz.to(D)).sum() + (wV * gw.to(D)).sum()).backward()
+    for name, t, w in zip(('Q', 'K', 'V', 'E1', 'E2', 'ye1', 'ye2'), dev, want):
+        assert rel(t.grad, w) <= 2e-5, (name, rel(t.grad, w))
+    # pairs with a padded end carry no gradient into the edge projections
+    dead = ~(nm[:, :, None] & nm[:, None, :])
+    assert torch.all(dev[3].grad.cpu()[dead] == 0) and torch.all(dev[4].grad.cpu()[dead] == 0)
+
+
+@pytest.mark.parametrize('Dw', [32, 64, 128, 256])
+def test_add_layernorm_backward(Dw):
+    from diffalign_amd.autograd_ops import AddLayerNorm
+    g = torch.Generator().manual_seed(Dw)
+    a, b = torch.randn(5, 33, Dw, generator=g).requires_grad_(), torch.randn(5, 33, Dw, generator=g).requires_grad_()
+    gam, bet = (torch.rand(Dw, generator=g) + 0.5).requires_grad_(), torch.randn(Dw, generator=g).requires_grad_()
+    gy = torch.randn(5, 33, Dw, generator=g)
+    ref = F.layer_norm(a + b, (Dw,), gam, bet, 1e-5)
+    (ref * gy).sum().backward()
+    dev = [t.detach().to(D).requires_grad_() for t in (a, b, gam, bet)]
+    out = AddLayerNorm.apply(*dev)
+    assert rel(out, ref) <= 1e-5
+    (out * gy.to(D)).sum().backward()
+    for name, t, w in zip('a b gamma beta'.split(), dev, (a, b, gam, bet)):
+        assert rel(t.grad, w.grad) <= 2e-5, (name, rel(t.grad, w.grad))
+
+
+def test_layernorm_backward_rejects_unbuilt_width():
+    from diffalign_amd import _lib as L
+    s = torch.randn(4, 48, device=D)
+    rc = L.lib().da_layernorm_bwd(L.ptr(s), L.ptr(torch.ones(48, device=D)), L.ptr(s), L.ptr(torch.empty_like(s)), L.ptr(torch.empty(48, device=D)),
+                                  L.ptr(torch.empty(48, device=D)), 4, 48, L.stream())
+    assert rc != 0 and 'width 48' in L.last_error()
+
+
+@pytest.mark.parametrize('shape', [(3, 17, 64), (2, 9, 9, 32), (2, 1, 8)])
+def test_pooled_statistics_forward_and_backward(shape):
+    from diffalign_amd.autograd_ops import PoolStats
+    g = torch.Generator().manual_seed(5)
+    Tt = torch.randn(*shape, generator=g).requires_grad_()
+    dims = tuple(range(1, len(shape) - 1))
+    N = int(np.prod(shape[1:-1]))
+    ref = O._stats4(Tt, dims) if N > 1 else torch.cat([Tt.mean(dims), Tt.amin(dims), Tt.amax(dims), torch.zeros(shape[0], shape[-1])], -1)
+    gz = torch.randn(shape[0], 4 * shape[-1], generator=g)
+    (ref * gz).sum().backward()
+    td = Tt.detach().to(D).requires_grad_()
+    out = PoolStats.apply(td)
+    if N > 1:
+        assert rel(out, ref) <= 1e-5
+    else:   # torch.std of one row is nan (the reference never pools a single row); the kernel returns 0 there
+        assert rel(out[:, :3 * shape[-1]], ref[:, :3 * shape[-1]]) <= 1e-6 and torch.all(out[:, 3 * shape[-1]:] == 0)
+    (out * gz.to(D)).sum().backward()
+    assert rel(td.grad, Tt.grad) <= 2e-5
+
+
+def test_hidden_mask_gradient():
+    from diffalign_amd.autograd_ops import MaskDense
+    from diffalign_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    nm = ragged_mask(3, 12, g)
+    X, E = torch.randn(3, 12, 16, generator=g).requires_grad_(), torch.randn(3, 12, 12, 8, generator=g).requires_grad_()
+    rX, rE = O.mask_dense(X, E, nm)
+    gX, gE = torch.randn(3, 12, 16, generator=g), torch.randn(3, 12, 12, 8, generator=g)
+    ((rX * gX).sum() + (rE * gE).sum()).backward()
+    Xd, Ed = X.detach().to(D).requires_grad_(), E.detach().to(D).requires_grad_()
+    oX, oE = MaskDense.apply(Xd, Ed, L.as_u8(nm.to(D)))
+    assert torch.equal(oX.cpu(), rX.detach()) and torch.equal(oE.cpu(), rE.detach())
+    ((oX * gX.to(D)).sum() + (oE * gE.to(D)).sum()).backward()
+    assert torch.equal(Xd.grad.cpu(), X.grad) and torch.equal(Ed.grad.cpu(), E.grad)
+
+
+def _train_inputs(z, data):
+    t = T(z['train_t']).float().to(D)
+    zt = data.get_new_object(X=F.one_hot(T(z['train_zt_X']), KX).float().to(D), E=F.one_hot(T(z['train_zt_E']), KE).float().to(D), y=t)
+    return t, zt
+
+
+def test_training_forward_matches_oracle_logits():
+    """The fp32 training forward (train_forward.py) == the oracle's denoiser on the same weights: 1e-4 absolute on logits of
+    magnitude ~10 (the fused bf16 inference path is held to 3e-2 relative on the same comparison)."""
+    z, model, data, pos = setup()
+    model.train()
+    t, zt = _train_inputs(z, data)
+    pred = model.forward(z_t=zt)
+    assert pred.X.requires_grad and pred.E.requires_grad
+    sd = {k: v.float() for k, v in weights_of(z).items()}
+    lX, lE, _ = O.denoiser_forward(sd, zt.X.cpu(), zt.E.cpu(), t.cpu(), T(z['node_mask']), 2, int(z['n_head']), (KX, KE, 1), T(z['am']), pos.cpu(),
+                                   T(z['mol']), True)
+    assert (pred.X.detach().cpu() - lX).abs().max() <= 1e-4 and (pred.E.detach().cpu() - lE).abs().max() <= 1e-4
+    model.eval()
+    with torch.no_grad():
+        pe = model.forward(z_t=zt)
+    assert not pe.X.requires_grad
+    assert (pe.X - pred.X.detach()).abs().max() <= 3e-2 * pred.X.detach().abs().max()
+
+
+@pytest.mark.parametrize('kind', ['ce', 'vb', 'vbce'])
+def test_parameter_gradients_match_oracle_autograd_and_reference_norms(kind):
+    z, model, data, pos = setup()
+    model.cfg.train.loss = kind
+    model.train()
+    t, zt = _train_inputs(z, data)
+    _, _, loss = model.training_step(data, 0, t_int=t, z_t=zt)
+    assert loss.requires_grad
+    loss.backward()
+    want_loss = float(z[f'train_{kind}_loss'])
+    assert abs(float(loss.detach()) - want_loss) <= 2e-5 * abs(want_loss) + 1e-5
+    _, sd, true, _ = _tiny_setup()
+    sd = {k: v.clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    oloss, _ = oracle_training_loss(z, sd, true, kind, pos=pos.cpu())
+    oloss.backward()
+    worst = ('', 0.0)
+    for name, p in model.model.named_parameters():
+        want = sd[name].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        err = float((p.grad.cpu() - want).norm()) / (float(want.norm()) + 1e-6)
+        if err > worst[1]: worst = (name, err)
+        assert err <= 1e-4, (name, err, float(want.norm()))
+    for pn in GNORM_PARAMS:
+        want, got = float(z[f'train_{kind}_gnorm::{pn}']), float(dict(model.model.named_parameters())[pn].grad.norm())
+        assert abs(got - want) <= 5e-4 * abs(want) + 1e-6, (pn, got, want)
+    print(f'[{kind}] loss {float(loss):.6f} (reference {want_loss:.6f}); worst parameter-gradient error {worst[1]:.2e} at {worst[0]}')
+    model.cfg.train.loss = 'ce'
+
+
+def test_vb_gradient_on_logits_vs_oracle():
+    """da_vb_grad alone: d elbo_batch_quick / d logits on random logits (every graph's t, one of them t == 1)."""
+    from diffalign_amd.autograd_ops import DiffusionLoss
+    from diffalign_amd import graph
+    z, model, data, _ = setup()
+    t, zt = _train_inputs(z, data)
+    assert int((t == 1).sum()) == 1
+    B, n = data.X.shape[:2]
+    g = torch.Generator().manual_seed(21)
+    lX, lE = (torch.randn(B, n, KX, generator=g) * 2).requires_grad_(), (torch.randn(B, n, n, KE, generator=g) * 2).requires_grad_()
+    masks = graph.get_node_masks(data, list(ATOMS), list(BONDS), 'product_and_sn', 'product_and_sn')
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, [28, 0], [4, 5, 6])
+    want = O.elbo_batch_quick(data.X.cpu(), data.E.cpu(), zt.X.cpu(), zt.E.cpu(), lX, lE, tabs, t.cpu()[:, 0], 10, masks[0].cpu().bool(),
+                              masks[1].cpu().bool(), 5.0)
+    want.backward()
+    dX, dE = lX.detach().to(D).requires_grad_(), lE.detach().to(D).requires_grad_()
+    got = DiffusionLoss.apply(dX, dE, model, data, zt, masks, 'vb')
+    assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want))
+    got.backward()
+    assert rel(dX.grad, lX.grad) <= 1e-4 and rel(dE.grad, lE.grad) <= 1e-4
+
+
+def test_fused_adamw_matches_torch():
+    from diffalign_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(2)
+    shapes = [(7, 5), (13,), (1,), (3, 4, 2)]
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    mine = [torch.nn.Parameter(p.clone().to(D)) for p in ps]
+    kw = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=True)
+    o_ref, o = torch.optim.AdamW(ref, **kw), FlatAdamW(mine, **kw)
+    for step in range(6):
+        o_ref.zero_grad(); o.zero_grad()
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g) * (10.0 if step == 1 else 1.0)     # a spike, so that amsgrad's running max matters
+            r.grad = gr.clone()
+            m.grad.add_(gr.to(D))                                                     # accumulate into the flat views, as autograd does
+        o_ref.step(); o.step()
+    for r, m in zip(ref, mine):
+        assert (m.detach().cpu() - r.detach()).abs().max() <= 1e-6
+    assert all(m.data_ptr() >= o.flat_param.data_ptr() for m in mine)                 # parameters live in the flat buffer
+
+
+def test_optimisation_steps_reduce_the_loss_and_refresh_the_inference_weights():
+    """train_one_step x 8 on one fixed batch (ce): the loss falls; with dropout > 0 the step stays finite; the fused bf16
+    inference path re-packs the updated weights (its loss follows the trained fp32 one)."""
+    from diffalign_amd.optim import FlatAdamW
+    z, model, data, pos = setup()
+    model.train()
+    t, zt = _train_inputs(z, data)
+    opt = FlatAdamW(model.model.parameters(), lr=2e-3)
+    losses = [float(model.train_one_step(data, opt, t_int=t, z_t=zt.get_new_object())) for _ in range(8)]
+    assert all(math.isfinite(l) for l in losses) and losses[-1] < 0.8 * losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        _, _, l_eval = model.training_step(data, 0, t_int=t, z_t=zt.get_new_object())
+    assert abs(float(l_eval) - losses[-1]) <= 0.15 * losses[0]
+    model.train()
+    for layer in model.model.tf_layers:
+        layer.dropout_p = 0.1
+    torch.manual_seed(0)
+    l_drop = float(model.train_one_step(data, opt, t_int=t, z_t=zt.get_new_object()))
+    assert math.isfinite(l_drop)
+    print('losses', [round(l, 4) for l in losses], 'eval', float(l_eval), 'with dropout', l_drop)

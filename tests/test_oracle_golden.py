@@ -184,6 +184,43 @@ def test_single_step_logits_and_chain_config0():
     assert np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
 
 
+def oracle_training_loss(z, sd, true, kind, pos=None, requires_grad=True):
+    """The three training objectives (diffusion_abstract.py:198-222) on the reference's recorded (t, z_t), differentiable in `sd`."""
+    from diffalign_amd import synthetic as S
+    if pos is None:
+        pos = S.shared_pos_encodings(dict(atom_map_numbers=true['atom_map_numbers']), 64, seed=73)
+    t = T(z['train_t']).float()
+    ztX, ztE = F.one_hot(T(z['train_zt_X']), KX).float(), F.one_hot(T(z['train_zt_E']), KE).float()
+    lX, lE, _ = O.denoiser_forward(sd, ztX, ztE, t, true['node_mask'], int(z['n_layers']), int(z['n_head']), (KX, KE, 1),
+                                   true['atom_map_numbers'], pos, true['mol_assignments'], True)
+    mx, me = O.free_masks(true['X'], true['node_mask'], true['atom_map_numbers'], 'product_and_sn', 28)
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    ce = O.ce_loss(lX, lE, true['X'], true['E'], mx, me, 5.0)[2]
+    if kind == 'ce':
+        return ce, (lX, lE)
+    vb = O.elbo_batch_quick(true['X'], true['E'], ztX, ztE, lX, lE, tabs, t[:, 0], 10, mx, me, 5.0)
+    return (vb if kind == 'vb' else vb + 2 * ce), (lX, lE)
+
+
+GNORM_PARAMS = ('mlp_in_E.0.weight', 'tf_layers.0.self_attn.e_out.weight', 'tf_layers.1.linE2.weight', 'mlp_out_X.2.weight', 'skip_scaling')
+
+
+@pytest.mark.parametrize('kind', ['ce', 'vb', 'vbce'])
+def test_training_losses_and_gradient_norms(kind):
+    """autograd through the oracle reproduces the loss values and the parameter-gradient norms that the reference's
+    own `loss.backward()` left (make_golden.py:432-469) -- this pins the checker the HIP backward is compared with."""
+    z, sd, true, _ = _tiny_setup()
+    sd = {k: v.clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    loss, _ = oracle_training_loss(z, sd, true, kind)
+    loss.backward()
+    assert abs(float(loss) - float(z[f'train_{kind}_loss'])) <= 2e-4 * abs(float(z[f'train_{kind}_loss'])) + 1e-4
+    for pn in GNORM_PARAMS:
+        want, got = float(z[f'train_{kind}_gnorm::{pn}']), float(sd[pn].grad.norm())
+        assert abs(got - want) <= 1e-3 * abs(want) + 1e-6, (pn, got, want)
+    for pn in ('mlp_out_y.0.weight', 'tf_layers.0.self_attn.y_y.weight', 'skip_scaling_3'):
+        assert sd[pn].grad is None
+
+
 def test_graph_utils_fix_duplicate_to_dense():
     """utils/graph.py fix_nodes_and_edges_by_idx / duplicate_data / to_dense against the reference's outputs."""
     z = load('graph_utils')
