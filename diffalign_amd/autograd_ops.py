@@ -16,6 +16,54 @@ def _c(t):
     return t.contiguous().float()
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch per device for the two-stage kernels (partial results); calls on one stream are ordered, so it is shared."""
+    w = _WS.get(device)
+    if w is None or w.numel() < nbytes:
+        w = _WS[device] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return w
+
+
+WIDE_MIN_ROWS = 4096          # below this the library's weight-gradient GEMM is as fast
+_WGRAD_SHAPES = {(64, 256), (256, 64), (64, 128), (128, 64), (64, 64), (128, 128)}
+
+
+class WideLinear(Function):
+    """nn.Linear over the (B,n,n) pairs.  Forward and dX are library GEMMs; dW / db -- a (out,in) result reduced over B n n rows, which
+    the library runs on a few workgroups -- go to da_linear_wgrad (split over rows, fp32 MFMA)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        out_f, in_f = weight.shape
+        dy = _c(dy)
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        R = x.numel() // in_f
+        x2, dy2 = _c(x).reshape(R, in_f), dy.reshape(R, out_f)
+        dW = torch.empty_like(weight); db = torch.empty(out_f, device=weight.device)
+        nbytes = L.lib().da_linear_wgrad_workspace(R, in_f, out_f)
+        ws = _workspace(x.device, nbytes)
+        L.check(L.lib().da_linear_wgrad(L.ptr(x2), L.ptr(dy2), L.ptr(dW), L.ptr(db), L.ptr(ws), ws.numel(), R, in_f, out_f, L.stream()),
+                'da_linear_wgrad')
+        return dx, dW, db
+
+
+def wide_linear(lin: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """`lin(x)` for per-pair inputs: WideLinear where da_linear_wgrad is built for the shape and the row count makes it pay."""
+    shape = (lin.in_features, lin.out_features)
+    if shape in _WGRAD_SHAPES and x.numel() // lin.in_features >= WIDE_MIN_ROWS and lin.bias is not None and torch.is_grad_enabled():
+        return WideLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class AttnCore(Function):
     """layers.py:225-265 between the q/k/v/e_mul/e_add projections and e_out / the y_x FiLM: (Q, K, V, E1, E2, ye1, ye2) ->
     (Z = ye1 + (ye2+1) Y, wV)."""
@@ -79,7 +127,9 @@ class PoolStats(Function):
         B, d = T.shape[0], T.shape[-1]
         N = T.numel() // (B * d)
         z = torch.empty(B, 4, d, device=T.device); arg = torch.empty(B, 2, d, dtype=torch.int32, device=T.device)
-        L.check(L.lib().da_pool_stats_fwd(L.ptr(T), L.ptr(z), L.ptr(arg), B, N, d, L.stream()), 'da_pool_stats_fwd')
+        ws = _workspace(T.device, 32 * B * 64 * d) if N > 256 else None
+        L.check(L.lib().da_pool_stats_fwd(L.ptr(T), L.ptr(z), L.ptr(arg), L.ptr(ws), ws.numel() if ws is not None else 0, B, N, d, L.stream()),
+                'da_pool_stats_fwd')
         ctx.save_for_backward(T, z, arg)
         return z.reshape(B, 4 * d)
 

@@ -41,8 +41,11 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ Q, c
   }
 }
 
-// Backward of the same: inputs dZ (B,n,n,dx), dwV (B,n,dx).  dK, dV (zero-filled by the caller) are summed over query rows with
-// fp32 atomics (the only non-deterministic sums of the training path); dye1, dye2 (B,dx, zero-filled) likewise, once per row.
+// Backward of the same: inputs dZ (B,n,n,dx), dwV (B,n,dx).  One workgroup per (graph, block of ATT_IB query rows), one thread per
+// channel: inside the key loop the ATT_IB rows share K_j, V_j and sum their dK_j, dV_j contributions in registers, so that only one
+// fp32 atomic per (block, key, channel) reaches dK / dV (zero-filled by the caller; the only order-dependent sums of the training path),
+// likewise one per block for dye1, dye2 (B,dx).
+#define ATT_IB 8
 __global__ void __launch_bounds__(256) k_attn_bwd(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
                                                   const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
@@ -50,33 +53,50 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const float* __restrict__ Q, c
                                                   const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
                                                   float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dE1,
                                                   float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
-  const int b = blockIdx.y, i = blockIdx.x;
-  const size_t row = (size_t)b * n + i;
-  const bool mi = nm[row] != 0;
+  const int b = blockIdx.y, i0 = blockIdx.x * ATT_IB;
+  const int ni = min(ATT_IB, n - i0);
   for (int c = threadIdx.x; c < dx; c += blockDim.x) {
-    const float q = Q[row * dx + c], f2 = ye2[(size_t)b * dx + c] + 1.f;
-    const float m = smax[row * dx + c], inv_l = 1.f / ssum[row * dx + c];
-    const float g = dwV[row * dx + c], D = g * wV[row * dx + c];          // sum_j attn_j * (dwV V_j)
-    float dq = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int j = 0; j < n; ++j) {
-      const size_t kj = ((size_t)b * n + j) * dx + c, off = (row * n + j) * dx + c;
-      const bool pm = mi && nm[(size_t)b * n + j] != 0;
-      const float k = K[kj], v = V[kj];
-      const float e1 = (pm ? E1[off] : 0.f) + 1.f, e2 = pm ? E2[off] : 0.f;
-      const float qk = (q * k) * qscale;
-      const float y = qk * e1 + e2;
-      const float attn = expf(y - m) * inv_l;
-      const float dz = dZ[off];
-      const float dy = dz * f2 + attn * (g * v - D);
-      d1 += dz; d2 += dz * y;
-      dE2[off] = pm ? dy : 0.f;
-      dE1[off] = pm ? dy * qk : 0.f;
-      const float dqk = dy * e1 * qscale;
-      dq += dqk * k;
-      atomicAdd(dK + kj, dqk * q);
-      atomicAdd(dV + kj, attn * g);
+    const float f2 = ye2[(size_t)b * dx + c] + 1.f;
+    float q[ATT_IB], m[ATT_IB], inv_l[ATT_IB], g[ATT_IB], D[ATT_IB], dq[ATT_IB];
+    bool mi[ATT_IB];
+#pragma unroll
+    for (int t = 0; t < ATT_IB; ++t) {
+      const size_t row = ((size_t)b * n + min(i0 + t, n - 1)) * dx + c;
+      q[t] = Q[row]; m[t] = smax[row]; inv_l[t] = 1.f / ssum[row]; g[t] = dwV[row]; D[t] = g[t] * wV[row];   // D = sum_j attn_j (dwV V_j)
+      dq[t] = 0.f; mi[t] = t < ni && nm[(size_t)b * n + i0 + t] != 0;
     }
-    dQ[row * dx + c] = dq;
+    float d1 = 0.f, d2 = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const size_t kj = ((size_t)b * n + j) * dx + c;
+      const bool mj = nm[(size_t)b * n + j] != 0;
+      const float k = K[kj], v = V[kj];
+      float dk = 0.f, dv = 0.f;
+#pragma unroll
+      for (int t = 0; t < ATT_IB; ++t) {
+        if (t < ni) {
+          const size_t off = (((size_t)b * n + i0 + t) * n + j) * dx + c;
+          const bool pm = mi[t] && mj;
+          const float e1 = (pm ? E1[off] : 0.f) + 1.f, e2 = pm ? E2[off] : 0.f;
+          const float qk = (q[t] * k) * qscale;
+          const float y = qk * e1 + e2;
+          const float attn = expf(y - m[t]) * inv_l[t];
+          const float dz = dZ[off];
+          const float dy = dz * f2 + attn * (g[t] * v - D[t]);
+          d1 += dz; d2 += dz * y;
+          dE2[off] = pm ? dy : 0.f;
+          dE1[off] = pm ? dy * qk : 0.f;
+          const float dqk = dy * e1 * qscale;
+          dq[t] += dqk * k;
+          dk += dqk * q[t];
+          dv += attn * g[t];
+        }
+      }
+      atomicAdd(dK + kj, dk);
+      atomicAdd(dV + kj, dv);
+    }
+#pragma unroll
+    for (int t = 0; t < ATT_IB; ++t)
+      if (t < ni) dQ[((size_t)b * n + i0 + t) * dx + c] = dq[t];
     atomicAdd(dye1 + (size_t)b * dx + c, d1);
     atomicAdd(dye2 + (size_t)b * dx + c, d2);
   }
@@ -128,34 +148,57 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ s, con
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Xtoy / Etoy: T (B,N,d) -> z (B,4,d) = [mean, min, max, unbiased std] over the N rows (padding included), arg (B,2,d) = row of the
-// min / max (first occurrence).  Workgroup = (graph, 64 channels), 256 threads = 4 row groups x 64 channels.
-__global__ void __launch_bounds__(256) k_pool_fwd(const float* __restrict__ T, float* __restrict__ z, int* __restrict__ arg, int N, int d) {
+// min / max (first occurrence).  Stage 1: workgroup = (64 channels, graph, slice of rows), 256 threads = 4 row groups x 64 channels,
+// partial (sum, sum of squares) in fp64 and (min, max, their rows) per slice; stage 2 folds the slices in row order.  With one
+// slice the two stages are one launch (S == 1 writes the result directly).
+struct PoolPart { double s, q; float mn, mx; int imn, imx; };
+static_assert(sizeof(PoolPart) == 32, "PoolPart layout");
+__device__ __forceinline__ void pool_write(const PoolPart& p, float* z, int* arg, int b, int c, int N, int d) {
+  const double mean = p.s / N;
+  const double var = N > 1 ? fmax(0.0, (p.q - p.s * mean) / (N - 1)) : 0.0;
+  float* o = z + (size_t)b * 4 * d;
+  o[c] = (float)mean; o[d + c] = p.mn; o[2 * d + c] = p.mx; o[3 * d + c] = (float)sqrt(var);
+  arg[((size_t)b * 2) * d + c] = p.imn; arg[((size_t)b * 2 + 1) * d + c] = p.imx;
+}
+__global__ void __launch_bounds__(256) k_pool_fwd(const float* __restrict__ T, float* __restrict__ z, int* __restrict__ arg,
+                                                  PoolPart* __restrict__ part, int N, int d, int rows_per_slice) {
   __shared__ double s_s[4][64], s_q[4][64];
   __shared__ float s_mn[4][64], s_mx[4][64];
   __shared__ int s_imn[4][64], s_imx[4][64];
   const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-  double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY; int imn = 0, imx = 0;
+  const int r0 = blockIdx.z * rows_per_slice, r1 = min(N, r0 + rows_per_slice);
+  PoolPart p{0.0, 0.0, INFINITY, -INFINITY, r0, r0};
   if (c < d)
-    for (int r = rg; r < N; r += 4) {
+    for (int r = r0 + rg; r < r1; r += 4) {
       const float v = T[((size_t)b * N + r) * d + c];
-      s += v; q += (double)v * v;
-      if (v < mn) { mn = v; imn = r; }
-      if (v > mx) { mx = v; imx = r; }
+      p.s += v; p.q += (double)v * v;
+      if (v < p.mn) { p.mn = v; p.imn = r; }
+      if (v > p.mx) { p.mx = v; p.imx = r; }
     }
-  s_s[rg][cl] = s; s_q[rg][cl] = q; s_mn[rg][cl] = mn; s_mx[rg][cl] = mx; s_imn[rg][cl] = imn; s_imx[rg][cl] = imx;
+  s_s[rg][cl] = p.s; s_q[rg][cl] = p.q; s_mn[rg][cl] = p.mn; s_mx[rg][cl] = p.mx; s_imn[rg][cl] = p.imn; s_imx[rg][cl] = p.imx;
   __syncthreads();
   if (rg == 0 && c < d) {
     for (int g = 1; g < 4; ++g) {
-      s += s_s[g][cl]; q += s_q[g][cl];
-      if (s_mn[g][cl] < mn || (s_mn[g][cl] == mn && s_imn[g][cl] < imn)) { mn = s_mn[g][cl]; imn = s_imn[g][cl]; }
-      if (s_mx[g][cl] > mx || (s_mx[g][cl] == mx && s_imx[g][cl] < imx)) { mx = s_mx[g][cl]; imx = s_imx[g][cl]; }
+      p.s += s_s[g][cl]; p.q += s_q[g][cl];
+      if (s_mn[g][cl] < p.mn || (s_mn[g][cl] == p.mn && s_imn[g][cl] < p.imn)) { p.mn = s_mn[g][cl]; p.imn = s_imn[g][cl]; }
+      if (s_mx[g][cl] > p.mx || (s_mx[g][cl] == p.mx && s_imx[g][cl] < p.imx)) { p.mx = s_mx[g][cl]; p.imx = s_imx[g][cl]; }
     }
-    const double mean = s / N;
-    const double var = N > 1 ? fmax(0.0, (q - s * mean) / (N - 1)) : 0.0;
-    float* o = z + (size_t)b * 4 * d;
-    o[c] = (float)mean; o[d + c] = mn; o[2 * d + c] = mx; o[3 * d + c] = (float)sqrt(var);
-    arg[((size_t)b * 2) * d + c] = imn; arg[((size_t)b * 2 + 1) * d + c] = imx;
+    if (gridDim.z == 1) pool_write(p, z, arg, b, c, N, d);
+    else part[((size_t)b * gridDim.z + blockIdx.z) * d + c] = p;
   }
+}
+__global__ void __launch_bounds__(64) k_pool_fold(const PoolPart* __restrict__ part, float* __restrict__ z, int* __restrict__ arg, int S, int N,
+                                                 int d) {
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= d) return;
+  PoolPart p = part[((size_t)b * S) * d + c];
+  for (int s = 1; s < S; ++s) {                                           // slices in row order: a strict comparison keeps the first row
+    const PoolPart o = part[((size_t)b * S + s) * d + c];
+    p.s += o.s; p.q += o.q;
+    if (o.mn < p.mn) { p.mn = o.mn; p.imn = o.imn; }
+    if (o.mx > p.mx) { p.mx = o.mx; p.imx = o.imx; }
+  }
+  pool_write(p, z, arg, b, c, N, d);
 }
 // dT = dmean / N + dstd (x - mean) / ((N-1) std) + [row == argmin] dmin + [row == argmax] dmax   (std = 0: that term is dropped)
 __global__ void __launch_bounds__(256) k_pool_bwd(const float* __restrict__ T, const float* __restrict__ z, const int* __restrict__ arg,
@@ -257,6 +300,92 @@ __global__ void __launch_bounds__(256) k_vb_grad(const float* __restrict__ tr, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Weight / bias gradient of a Linear applied to every pair: dW (OUT,IN) = dY^T X, db = column sums of dY, with X (R,IN), dY (R,OUT)
+// and R = B n n rows (313,600 at B = 16, n = 140) -- a contraction with a tiny result and a huge reduction axis, which the library
+// runs on a handful of workgroups (0.58 - 0.73 ms each, 30 % of the training step: profiles/r02/train_kernel_stats_a.csv).
+// Here: split over R.  Each workgroup (4 waves) owns a slice of rows and the whole (OUT,IN) result in accumulators, as 32x32 tiles
+// of v_mfma_f32_32x32x2_f32 (true fp32).  For that instruction lane l supplies A[m = l % 32][k = l / 32] and B[k = l / 32][n = l % 32]:
+// with m = output feature, n = input feature and k = two consecutive rows, both operands are plain coalesced row reads from HBM
+// (no LDS, no transposes).  Stage 2 sums the slices' partial results in slice order (deterministic).
+template <int IN, int OUT, int WI, int WJ>
+__global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ part,
+                                                       float* __restrict__ bpart, long long R, int rows_per_wg) {
+  static_assert(WI * WJ == 4 && (IN / 32) % WI == 0 && (OUT / 32) % WJ == 0, "tiling");
+  constexpr int TI = IN / 32 / WI, TJ = OUT / 32 / WJ;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l32 = lane & 31, lh = lane >> 5;
+  const int wi = w / WJ, wj = w % WJ;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  f32x16 acc[TJ][TI];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[tj][ti][v] = 0.f;
+  float bs[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) bs[tj] = 0.f;
+  const float* xp = X + (wi * TI) * 32 + l32;
+  const float* yp = dY + (wj * TJ) * 32 + l32;
+#pragma unroll 4
+  for (long long r = r0; r < r1; r += 2) {
+    const long long rr = r + lh;
+    const bool ok = rr < r1;
+    float a[TJ], bb[TI];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) { a[tj] = ok ? yp[rr * OUT + tj * 32] : 0.f; bs[tj] += a[tj]; }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) bb[ti] = ok ? xp[rr * IN + ti * 32] : 0.f;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tj], bb[ti], acc[tj][ti], 0, 0, 0);
+  }
+  float* pw = part + (size_t)blockIdx.x * OUT * IN;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int o = (wj * TJ + tj) * 32 + 8 * (v >> 2) + 4 * lh + (v & 3), i = (wi * TI + ti) * 32 + l32;
+        pw[(size_t)o * IN + i] = acc[tj][ti][v];
+      }
+  if (wi == 0) {
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float t = bs[tj] + __shfl_xor(bs[tj], 32);
+      if (lh == 0) bpart[(size_t)blockIdx.x * OUT + (wj * TJ + tj) * 32 + l32] = t;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dW,
+                                                    float* __restrict__ db, int G, int nW, int nB) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nW) {
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(size_t)g * nW + t];
+    dW[t] = s;
+  } else if (t < nW + nB && db) {
+    const int c = t - nW;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += bpart[(size_t)g * nB + c];
+    db[c] = s;
+  }
+}
+#define WGRAD_MAX_SLICES 512
+template <int IN, int OUT, int WI, int WJ>
+static void launch_wgrad(const float* X, const float* dY, float* dW, float* db, float* ws, long long R, hipStream_t s) {
+  long long per = (R + WGRAD_MAX_SLICES - 1) / WGRAD_MAX_SLICES;
+  per = (per + 1) & ~1LL;                                                 // rows are consumed in pairs
+  if (per < 64) per = 64;
+  const int G = (int)((R + per - 1) / per);
+  float* bpart = ws + (size_t)G * OUT * IN;
+  k_wgrad_partial<IN, OUT, WI, WJ><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
+  k_wgrad_fold<<<(IN * OUT + OUT + 255) / 256, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // AdamW(amsgrad) on a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay, bias corrections by step).
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                float* __restrict__ vmax, long long N, float lr, float b1, float b2, float eps, float wd,
@@ -311,7 +440,7 @@ int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float
   const size_t nb = sizeof(float) * (size_t)B * n * dx, yb = sizeof(float) * (size_t)B * dx;
   if (hipMemsetAsync(dK, 0, nb, s) != hipSuccess || hipMemsetAsync(dV, 0, nb, s) != hipSuccess || hipMemsetAsync(dye1, 0, yb, s) != hipSuccess ||
       hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) { da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP; }
-  k_attn_bwd<<<dim3(n, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV,
+  k_attn_bwd<<<dim3((n + ATT_IB - 1) / ATT_IB, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV,
                                                                        dE1, dE2, dye1, dye2, n, dx);
   DA_CHECK_LAUNCH("da_attn_core_bwd");
   return DA_OK;
@@ -337,10 +466,17 @@ int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float*
   return DA_OK;
 }
 
-int da_pool_stats_fwd(const float* T, float* z, int* arg, int B, int N, int d, void* stream) {
+int da_pool_stats_fwd(const float* T, float* z, int* arg, void* workspace, long long workspace_bytes, int B, int N, int d, void* stream) {
   DA_CHECK_ARG(B >= 0 && N >= 1 && d >= 1, "da_pool_stats_fwd: sizes");
   if (B == 0) return DA_OK;
-  k_pool_fwd<<<dim3((d + 63) / 64, B), 256, 0, (hipStream_t)stream>>>(T, z, arg, N, d);
+  hipStream_t s = (hipStream_t)stream;
+  int S = (N + 255) / 256;                                                // >= 256 rows per slice
+  if (S > 64) S = 64;
+  if (!workspace || workspace_bytes < (long long)sizeof(PoolPart) * B * S * d) S = 1;   // no room for partials: one slice per graph
+  const int per = (N + S - 1) / S;
+  S = (N + per - 1) / per;
+  k_pool_fwd<<<dim3((d + 63) / 64, B, S), 256, 0, s>>>(T, z, arg, (PoolPart*)workspace, N, d, per);
+  if (S > 1) k_pool_fold<<<dim3((d + 63) / 64, B), 64, 0, s>>>((const PoolPart*)workspace, z, arg, S, N, d);
   DA_CHECK_LAUNCH("da_pool_stats_fwd");
   return DA_OK;
 }
@@ -350,6 +486,32 @@ int da_pool_stats_bwd(const float* T, const float* z, const int* arg, const floa
   const long long total = (long long)B * N * d;
   k_pool_bwd<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(T, z, arg, dz, dT, N, d, total);
   DA_CHECK_LAUNCH("da_pool_stats_bwd");
+  return DA_OK;
+}
+
+long long da_linear_wgrad_workspace(long long R, int in_features, int out_features) {
+  (void)R;
+  return (long long)sizeof(float) * WGRAD_MAX_SLICES * ((long long)in_features * out_features + out_features);
+}
+int da_linear_wgrad(const float* X, const float* dY, float* dW, float* db, void* workspace, long long workspace_bytes, long long R,
+                    int in_features, int out_features, void* stream) {
+  DA_CHECK_ARG(R >= 1 && X && dY && dW && workspace, "da_linear_wgrad: arguments");
+  DA_CHECK_ARG(workspace_bytes >= da_linear_wgrad_workspace(R, in_features, out_features), "da_linear_wgrad: workspace of %lld bytes is too small",
+               workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int key = in_features * 1000 + out_features;
+  switch (key) {
+    case 64256: launch_wgrad<64, 256, 1, 4>(X, dY, dW, db, ws, R, s); break;      // e_mul, e_add
+    case 256064: launch_wgrad<256, 64, 4, 1>(X, dY, dW, db, ws, R, s); break;     // e_out
+    case 64128: launch_wgrad<64, 128, 1, 4>(X, dY, dW, db, ws, R, s); break;      // linE1, mlp_out_E.0
+    case 128064: launch_wgrad<128, 64, 4, 1>(X, dY, dW, db, ws, R, s); break;     // linE2, mlp_in_E.2
+    case 64064: launch_wgrad<64, 64, 2, 2>(X, dY, dW, db, ws, R, s); break;
+    case 128128: launch_wgrad<128, 128, 2, 2>(X, dY, dW, db, ws, R, s); break;
+    default: da_set_error("da_linear_wgrad: %d -> %d features not built (64->256, 256->64, 64->128, 128->64, 64->64, 128->128)", in_features,
+                          out_features); return DA_ERR_UNSUPPORTED;
+  }
+  DA_CHECK_LAUNCH("da_linear_wgrad");
   return DA_OK;
 }
 

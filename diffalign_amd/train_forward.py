@@ -2,7 +2,8 @@
 
 Same arithmetic as GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713) and
 XEyTransformerLayer / NodeEdgeBlock (neuralnet/layers.py:204-361) in train mode, laid out for a backward pass:
-  * every nn.Linear is called as the torch module it is (library GEMM; autograd supplies both backward products);
+  * every nn.Linear is a library GEMM under autograd, except that the weight gradients of the per-pair Linears (a (out,in) result
+    reduced over B n n rows) come from da_linear_wgrad (autograd_ops.WideLinear);
   * the per-pair attention core, the LayerNorms, the pooled statistics and the hidden-feature mask are HIP autograd.Functions
     (diffalign_amd/autograd_ops.py);
   * masks, residual adds, ReLU, dropout, the symmetrisation and the product->reactant skip gather are torch elementwise glue.
@@ -16,14 +17,14 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .autograd_ops import AttnCore, AddLayerNorm, PoolStats, MaskDense, qscale_of
+from .autograd_ops import AttnCore, AddLayerNorm, PoolStats, MaskDense, qscale_of, wide_linear
 
 
 def _node_edge_block(a, X, E, y, nm_u8, xm, em):
     """layers.py:204-284."""
     Q, K, V = a.q(X) * xm, a.k(X) * xm, a.v(X) * xm
-    Z, wV = AttnCore.apply(Q, K, V, a.e_mul(E), a.e_add(E), nm_u8, a.y_e_add(y), a.y_e_mul(y), qscale_of(a.dx, a.n_head))
-    newE = a.e_out(Z) * em
+    Z, wV = AttnCore.apply(Q, K, V, wide_linear(a.e_mul, E), wide_linear(a.e_add, E), nm_u8, a.y_e_add(y), a.y_e_mul(y), qscale_of(a.dx, a.n_head))
+    newE = wide_linear(a.e_out, Z) * em
     newX = a.x_out(a.y_x_add(y)[:, None, :] + (a.y_x_mul(y)[:, None, :] + 1) * wV) * xm
     new_y = a.y_out(y + a.x_y.lin(PoolStats.apply(X)) + a.e_y.lin(PoolStats.apply(E)))
     return newX, newE, new_y
@@ -37,7 +38,7 @@ def _layer(layer, X, E, y, nm_u8, xm, em, training):
     E = AddLayerNorm.apply(E, drop(nE), layer.normE1.weight, layer.normE1.bias)
     y = AddLayerNorm.apply(y, drop(ny), layer.norm_y1.weight, layer.norm_y1.bias)
     X = AddLayerNorm.apply(X, drop(layer.linX2(drop(F.relu(layer.linX1(X))))), layer.normX2.weight, layer.normX2.bias)
-    E = AddLayerNorm.apply(E, drop(layer.linE2(drop(F.relu(layer.linE1(E))))), layer.normE2.weight, layer.normE2.bias)
+    E = AddLayerNorm.apply(E, drop(wide_linear(layer.linE2, drop(F.relu(wide_linear(layer.linE1, E))))), layer.normE2.weight, layer.normE2.bias)
     y = AddLayerNorm.apply(y, drop(layer.lin_y2(drop(F.relu(layer.lin_y1(y))))), layer.norm_y2.weight, layer.norm_y2.bias)
     return X, E, y
 
@@ -51,7 +52,8 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
     nm_u8 = L.as_u8(node_mask)
     xm = node_mask[:, :, None].float()
     em = xm[:, :, None, :] * xm[:, None, :, :]
-    Xh, Eh, yh = m.mlp_in_X(X), m.mlp_in_E(E), m.mlp_in_y(y)
+    Xh, yh = m.mlp_in_X(X), m.mlp_in_y(y)
+    Eh = F.relu(wide_linear(m.mlp_in_E[2], F.relu(m.mlp_in_E[0](E))))
     Eh = (Eh + Eh.transpose(1, 2)) / 2
     Xh, Eh = MaskDense.apply(Xh, Eh, nm_u8)
     if pos_encodings is not None:
@@ -60,7 +62,7 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
         Xh, Eh, yh = _layer(layer, Xh, Eh, yh, nm_u8, xm, em, m.training)
     kx, ke, ky = m.out_dim_X, m.out_dim_E, m.out_dim_y
     Xo = m.mlp_out_X(Xh) + X[..., :kx]
-    Eo = (m.mlp_out_E(Eh) + E[..., :ke]) * (~torch.eye(n, dtype=torch.bool, device=X.device))[None, :, :, None]
+    Eo = (m.mlp_out_E[2](F.relu(wide_linear(m.mlp_out_E[0], Eh))) + E[..., :ke]) * (~torch.eye(n, dtype=torch.bool, device=X.device))[None, :, :, None]
     Eo = 0.5 * (Eo + Eo.transpose(1, 2))
     yo = yh[..., :ky] + y[..., :ky]
     if getattr(m, 'p_to_r_skip_connection', False):

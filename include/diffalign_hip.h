@@ -143,17 +143,25 @@ int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float
                      const float* ye1, const float* ye2, float qscale, float* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
                      void* stream);
 /* Its backward: from dZ (B,n,n,dx) and dwV (B,n,dx) to dQ, dK, dV (B,n,dx), dE1, dE2 (B,n,n,dx; zero on masked pairs), dye1, dye2
- * (B,dx).  dK, dV, dye1, dye2 are cleared here and summed with fp32 atomics (order-dependent in the last bits). */
+ * (B,dx).  dK, dV, dye1, dye2 are cleared here and summed with fp32 atomics, one per block of 8 query rows (order-dependent in the last bits). */
 int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
                      const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const float* dZ, const float* dwV,
                      float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, int B, int n, int dx, void* stream);
+/* Weight and bias gradient of an nn.Linear applied to R rows (training/helpers.py:139 `loss.backward()` for the per-pair Linears e_mul,
+ * e_add, e_out, linE1, linE2, mlp_in_E.2, mlp_out_E.0, where R = B n n): dW (out,in) = dY^T X, db (out) = column sums of dY (NULL: skipped);
+ * X (R,in), dY (R,out) fp32 row-major.  Split over R, fp32 MFMA, partial results in `workspace` (da_linear_wgrad_workspace bytes), summed in
+ * slice order.  Built for (in,out) in {(64,256), (256,64), (64,128), (128,64), (64,64), (128,128)}; others: DA_ERR_UNSUPPORTED. */
+long long da_linear_wgrad_workspace(long long R, int in_features, int out_features);
+int da_linear_wgrad(const float* X, const float* dY, float* dW, float* db, void* workspace, long long workspace_bytes, long long R,
+                    int in_features, int out_features, void* stream);
 /* LayerNorm backward (eps 1e-5; layers.py:341-359): s (rows,D) = the normalised input, dy the gradient of gamma * xhat + beta ->
  * ds (rows,D), dgamma (D), dbeta (D).  D in {32, 64, 128, 256}. */
 int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, long long rows, int D,
                      void* stream);
 /* Xtoy / Etoy pooled statistics (layers.py:15-47) of T (B,N,d): z (B,4,d) = [mean, min, max, unbiased std] over the N rows, arg
- * (B,2,d) int32 = row index of the min / max (first occurrence); and the backward dT from dz. */
-int da_pool_stats_fwd(const float* T, float* z, int* arg, int B, int N, int d, void* stream);
+ * (B,2,d) int32 = row index of the min / max (first occurrence); and the backward dT from dz.  workspace: room for the per-slice
+ * partial results, 32 * B * 64 * d bytes covers every N (NULL / too small: one workgroup column per graph, slow for N = n*n). */
+int da_pool_stats_fwd(const float* T, float* z, int* arg, void* workspace, long long workspace_bytes, int B, int N, int d, void* stream);
 int da_pool_stats_bwd(const float* T, const float* z, const int* arg, const float* dz, float* dT, int B, int N, int d, void* stream);
 /* d elbo_batch_quick / d logits (elbo.py:273-334, avg_over_batch=True): free rows of graphs with t > 1 carry the log-space
  * KL(q(z_s|z_t,x_0) || p(z_s|z_t)) of compute_Lt (helpers.py:772-781), graphs with t == 1 (t_is_1[b] != 0) carry -log p(x_0).

@@ -107,6 +107,71 @@ def test_pooled_statistics_forward_and_backward(shape):
     assert rel(td.grad, Tt.grad) <= 2e-5
 
 
+@pytest.mark.parametrize('fin,fout', [(64, 256), (256, 64), (64, 128), (128, 64), (64, 64), (128, 128)])
+def test_wide_linear_weight_gradient(fin, fout):
+    """da_linear_wgrad (split over rows, fp32 MFMA, ordered fold) == torch's dY^T X and column sums; ragged row counts."""
+    from diffalign_amd.autograd_ops import WideLinear
+    from diffalign_amd import _lib as L
+    g = torch.Generator().manual_seed(fin + fout)
+    for R in (1, 63, 1000, 70001):
+        x, w, b = torch.randn(R, fin, generator=g), torch.randn(fout, fin, generator=g) * 0.1, torch.randn(fout, generator=g)
+        gy = torch.randn(R, fout, generator=g)
+        xd, wd, bd = (t.to(D).requires_grad_() for t in (x, w, b))
+        out = WideLinear.apply(xd, wd, bd)
+        out.backward(gy.to(D))
+        xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+        F.linear(xr, wr, br).backward(gy.double())
+        assert rel(out, F.linear(x, w, b)) <= 1e-5
+        assert rel(wd.grad, wr.grad) <= 5e-6 and rel(bd.grad, br.grad) <= 5e-6 and rel(xd.grad, xr.grad) <= 1e-5, (R, rel(wd.grad, wr.grad))
+    rc = L.lib().da_linear_wgrad(L.ptr(xd.detach()), L.ptr(xd.detach()), L.ptr(wd.detach()), None, L.ptr(xd.detach()), 1 << 40, 8, 48, 48, L.stream())
+    assert rc != 0 and 'not built' in L.last_error()
+
+
+def test_full_width_layers_gradients_vs_oracle():
+    """align_absorbing widths (dx 256, de 64, dy 64, 8 heads), 2 layers, ragged B=3 x n=26: every parameter's gradient of a random
+    linear functional of the logits, training forward + HIP backward vs autograd through the oracle (fp32 CPU).  The per-pair Linears
+    take the WideLinear path here (the tiny golden model's widths do not)."""
+    import torch.nn as nn
+    from bench import FULL
+    from diffalign_amd import autograd_ops, synthetic as S
+    from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
+    torch.manual_seed(4)
+    B, n = 3, 26
+    m = GraphTransformerWithYAtomMapPosEmb(2, {'X': KX + 8, 'E': KE, 'y': 13}, FULL['hidden_mlp_dims'], FULL['hidden_dims'],
+                                           {'X': KX, 'E': KE, 'y': 1}, nn.ReLU(), nn.ReLU(), dropout=0.0, p_to_r_skip_connection=True,
+                                           p_to_r_init=1.0, alignment_type='correct')
+    true = S.make_reaction_batch(B, n, seed=5, P=None)
+    g = torch.Generator().manual_seed(6)
+    X = torch.cat([true['X'], torch.rand(B, n, 8, generator=g)], -1)
+    y = torch.rand(B, 13, generator=g)
+    pos = S.shared_pos_encodings(true, 256, seed=7)
+    gX, gE = torch.randn(B, n, KX, generator=g), torch.randn(B, n, n, KE, generator=g)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    lX, lE, _ = O.denoiser_forward(sd, X, true['E'], y, true['node_mask'], 2, 8, (KX, KE, 1), true['atom_map_numbers'], pos,
+                                   true['mol_assignments'], True)
+    ((lX * gX).sum() + (lE * gE).sum()).backward()
+    m = m.to(D).train()
+    old = autograd_ops.WIDE_MIN_ROWS
+    autograd_ops.WIDE_MIN_ROWS = 1
+    try:
+        Xo, Eo, _, _ = m(X.to(D), true['E'].to(D), y.to(D), true['node_mask'].to(D), true['atom_map_numbers'].to(D), pos.to(D),
+                         true['mol_assignments'].to(D))
+        assert (Xo.detach().cpu() - lX.detach()).abs().max() <= 2e-4 and (Eo.detach().cpu() - lE.detach()).abs().max() <= 2e-4
+        ((Xo * gX.to(D)).sum() + (Eo * gE.to(D)).sum()).backward()
+    finally:
+        autograd_ops.WIDE_MIN_ROWS = old
+    worst = ('', 0.0)
+    for name, p in m.named_parameters():
+        want = sd[name].grad
+        if want is None:
+            assert p.grad is None, name
+            continue
+        err = float((p.grad.cpu() - want).norm()) / (float(want.norm()) + 1e-6)
+        if err > worst[1]: worst = (name, err)
+        assert err <= 2e-4, (name, err)
+    print('worst full-width parameter-gradient error', worst)
+
+
 def test_hidden_mask_gradient():
     from diffalign_amd.autograd_ops import MaskDense
     from diffalign_amd import _lib as L
