@@ -16,6 +16,12 @@ def _c(t):
     return t.contiguous().float()
 
 
+def _c16(t):
+    """contiguous fp32 at a 16-byte aligned address (kernels that read float4)."""
+    t = _c(t)
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 _WS = {}
 
 
@@ -98,7 +104,7 @@ class AddLayerNorm(Function):
 
     @staticmethod
     def forward(ctx, a, b, gamma, beta):
-        s = _c(a) + _c(b)
+        s = _c(a) + _c(b)                  # a fresh allocation: 16-byte aligned
         D = s.shape[-1]
         out = torch.empty_like(s)
         g, be = _c(gamma), _c(beta)
@@ -111,10 +117,11 @@ class AddLayerNorm(Function):
     def backward(ctx, dy):
         s, g = ctx.saved_tensors
         D = s.shape[-1]
-        dy = _c(dy)
+        dy = _c16(dy)
         ds = torch.empty_like(s); dg = torch.empty(D, device=s.device); db = torch.empty(D, device=s.device)
-        L.check(L.lib().da_layernorm_bwd(L.ptr(s), L.ptr(g), L.ptr(dy), L.ptr(ds), L.ptr(dg), L.ptr(db), s.numel() // D, D, L.stream()),
-                'da_layernorm_bwd')
+        ws = _workspace(s.device, 8 * 1024 * D)
+        L.check(L.lib().da_layernorm_bwd(L.ptr(s), L.ptr(g), L.ptr(dy), L.ptr(ds), L.ptr(dg), L.ptr(db), L.ptr(ws), ws.numel(), s.numel() // D, D,
+                                         L.stream()), 'da_layernorm_bwd')
         return ds, ds, dg, db
 
 

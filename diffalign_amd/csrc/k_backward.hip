@@ -12,6 +12,7 @@
 // here in fp32 (321 MB each at B = 16, n = 140), as the reference does; everything is HBM-bound streaming.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // NodeEdgeBlock core.  One workgroup per query row (b,i), one thread per channel (strided when dx > blockDim).
@@ -41,109 +42,138 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const float* __restrict__ Q, c
   }
 }
 
-// Backward of the same: inputs dZ (B,n,n,dx), dwV (B,n,dx).  One workgroup per (graph, block of ATT_IB query rows), one thread per
-// channel: inside the key loop the ATT_IB rows share K_j, V_j and sum their dK_j, dV_j contributions in registers, so that only one
-// fp32 atomic per (block, key, channel) reaches dK / dV (zero-filled by the caller; the only order-dependent sums of the training path),
-// likewise one per block for dye1, dye2 (B,dx).
-#define ATT_IB 8
-__global__ void __launch_bounds__(256) k_attn_bwd(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                  const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
-                                                  const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
-                                                  const float* __restrict__ smax, const float* __restrict__ ssum,
-                                                  const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
-                                                  float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dE1,
-                                                  float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
+// Backward of the same: inputs dZ (B,n,n,dx), dwV (B,n,dx).  One workgroup per (graph, block of ATT_IB query rows); threads =
+// (channel, key slice): slice s walks the keys j = s, s + ATT_JS, ...  Inside the key loop the ATT_IB rows share K_j, V_j and sum
+// their dK_j, dV_j contributions in registers, so that one fp32 atomic per (block, key, channel) reaches dK / dV (zero-filled by the
+// caller; the only order-dependent sums of the training path); dQ, dye1, dye2 are folded over the slices in LDS, then one atomic per
+// block for dye1, dye2 (B,dx).
+template <int ATT_IB, int ATT_JS>
+__global__ void __launch_bounds__(256 * ATT_JS) k_attn_bwd(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                   const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
+                                                   const float* __restrict__ smax, const float* __restrict__ ssum,
+                                                   const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
+                                                   float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dE1,
+                                                   float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
+  extern __shared__ float s_red[];                                        // [ATT_JS][ATT_IB + 2][CW]
+  const int CW = blockDim.x / ATT_JS;                                     // channels per pass
+  const int cl = threadIdx.x % CW, js = threadIdx.x / CW;
   const int b = blockIdx.y, i0 = blockIdx.x * ATT_IB;
   const int ni = min(ATT_IB, n - i0);
-  for (int c = threadIdx.x; c < dx; c += blockDim.x) {
-    const float f2 = ye2[(size_t)b * dx + c] + 1.f;
-    float q[ATT_IB], m[ATT_IB], inv_l[ATT_IB], g[ATT_IB], D[ATT_IB], dq[ATT_IB];
-    bool mi[ATT_IB];
+  for (int c0 = 0; c0 < dx; c0 += CW) {
+    const int c = c0 + cl;
+    const bool cok = c < dx;
+    float dq[ATT_IB], d1 = 0.f, d2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < ATT_IB; ++t) {
-      const size_t row = ((size_t)b * n + min(i0 + t, n - 1)) * dx + c;
-      q[t] = Q[row]; m[t] = smax[row]; inv_l[t] = 1.f / ssum[row]; g[t] = dwV[row]; D[t] = g[t] * wV[row];   // D = sum_j attn_j (dwV V_j)
-      dq[t] = 0.f; mi[t] = t < ni && nm[(size_t)b * n + i0 + t] != 0;
-    }
-    float d1 = 0.f, d2 = 0.f;
-    for (int j = 0; j < n; ++j) {
-      const size_t kj = ((size_t)b * n + j) * dx + c;
-      const bool mj = nm[(size_t)b * n + j] != 0;
-      const float k = K[kj], v = V[kj];
-      float dk = 0.f, dv = 0.f;
+    for (int t = 0; t < ATT_IB; ++t) dq[t] = 0.f;
+    if (cok) {
+      const float f2 = ye2[(size_t)b * dx + c] + 1.f;
+      float q[ATT_IB], m[ATT_IB], inv_l[ATT_IB], g[ATT_IB], D[ATT_IB];
+      bool mi[ATT_IB];
 #pragma unroll
       for (int t = 0; t < ATT_IB; ++t) {
-        if (t < ni) {
-          const size_t off = (((size_t)b * n + i0 + t) * n + j) * dx + c;
-          const bool pm = mi[t] && mj;
-          const float e1 = (pm ? E1[off] : 0.f) + 1.f, e2 = pm ? E2[off] : 0.f;
-          const float qk = (q[t] * k) * qscale;
-          const float y = qk * e1 + e2;
-          const float attn = expf(y - m[t]) * inv_l[t];
-          const float dz = dZ[off];
-          const float dy = dz * f2 + attn * (g[t] * v - D[t]);
-          d1 += dz; d2 += dz * y;
-          dE2[off] = pm ? dy : 0.f;
-          dE1[off] = pm ? dy * qk : 0.f;
-          const float dqk = dy * e1 * qscale;
-          dq[t] += dqk * k;
-          dk += dqk * q[t];
-          dv += attn * g[t];
-        }
+        const size_t row = ((size_t)b * n + min(i0 + t, n - 1)) * dx + c;
+        q[t] = Q[row]; m[t] = smax[row]; inv_l[t] = 1.f / ssum[row]; g[t] = dwV[row]; D[t] = g[t] * wV[row];   // D = sum_j attn_j (dwV V_j)
+        mi[t] = t < ni && nm[(size_t)b * n + i0 + t] != 0;
       }
-      atomicAdd(dK + kj, dk);
-      atomicAdd(dV + kj, dv);
-    }
+      for (int j = js; j < n; j += ATT_JS) {
+        const size_t kj = ((size_t)b * n + j) * dx + c;
+        const bool mj = nm[(size_t)b * n + j] != 0;
+        const float k = K[kj], v = V[kj];
+        float dk = 0.f, dv = 0.f;
 #pragma unroll
-    for (int t = 0; t < ATT_IB; ++t)
-      if (t < ni) dQ[((size_t)b * n + i0 + t) * dx + c] = dq[t];
-    atomicAdd(dye1 + (size_t)b * dx + c, d1);
-    atomicAdd(dye2 + (size_t)b * dx + c, d2);
+        for (int t = 0; t < ATT_IB; ++t) {
+          if (t < ni) {
+            const size_t off = (((size_t)b * n + i0 + t) * n + j) * dx + c;
+            const bool pm = mi[t] && mj;
+            const float e1 = (pm ? E1[off] : 0.f) + 1.f, e2 = pm ? E2[off] : 0.f;
+            const float qk = (q[t] * k) * qscale;
+            const float y = qk * e1 + e2;
+            const float attn = expf(y - m[t]) * inv_l[t];
+            const float dz = dZ[off];
+            const float dy = dz * f2 + attn * (g[t] * v - D[t]);
+            d1 += dz; d2 += dz * y;
+            dE2[off] = pm ? dy : 0.f;
+            dE1[off] = pm ? dy * qk : 0.f;
+            const float dqk = dy * e1 * qscale;
+            dq[t] += dqk * k;
+            dk += dqk * q[t];
+            dv += attn * g[t];
+          }
+        }
+        atomicAdd(dK + kj, dk);
+        atomicAdd(dV + kj, dv);
+      }
+    }
+    __syncthreads();                                                      // s_red of the previous channel pass has been read
+    float* mine = s_red + (size_t)js * (ATT_IB + 2) * CW + cl;
+#pragma unroll
+    for (int t = 0; t < ATT_IB; ++t) mine[t * CW] = dq[t];
+    mine[ATT_IB * CW] = d1; mine[(ATT_IB + 1) * CW] = d2;
+    __syncthreads();
+    if (js == 0 && cok) {
+      for (int s2 = 1; s2 < ATT_JS; ++s2) {
+        const float* o = s_red + (size_t)s2 * (ATT_IB + 2) * CW + cl;
+#pragma unroll
+        for (int t = 0; t < ATT_IB; ++t) dq[t] += o[t * CW];
+        d1 += o[ATT_IB * CW]; d2 += o[(ATT_IB + 1) * CW];
+      }
+#pragma unroll
+      for (int t = 0; t < ATT_IB; ++t)
+        if (t < ni) dQ[((size_t)b * n + i0 + t) * dx + c] = dq[t];
+      atomicAdd(dye1 + (size_t)b * dx + c, d1);
+      atomicAdd(dye2 + (size_t)b * dx + c, d2);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// LayerNorm backward, eps 1e-5.  s = the normalised input (a + b of the residual), one wave per row, grid-stride over rows;
-// dgamma / dbeta (zero-filled) receive one atomic per lane element per wave.
+// LayerNorm backward, eps 1e-5.  s = the normalised input (a + b of the residual).  A row of D floats is held by D/4 lanes as one
+// float4 each (16-byte loads), so a wave covers 256/D rows per pass; grid-stride over rows.  dgamma / dbeta: per-workgroup partial
+// sums (pg, pb: (gridDim.x, D)), folded afterwards by k_wgrad_fold -- thousands of atomics on the same 2 D addresses serialise in L2
+// (measured: 0.27 ms of a 0.3 ms launch).
 template <int D>
 __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ dy,
-                                                float* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows) {
-  constexpr int PER = (D + 63) / 64;
-  const int lane = threadIdx.x & 63;
+                                                float* __restrict__ ds, float* __restrict__ pg, float* __restrict__ pb, long long rows) {
+  __shared__ float s_g[4][D], s_b[4][D];
+  constexpr int LPR = D / 4, RPW = 64 / LPR;                              // lanes per row, rows per wave pass
+  const int lane = threadIdx.x & 63, lr = lane % LPR, rw = lane / LPR;
   const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
-  float gm[PER], ag[PER], ab[PER];
+  const f32x4 gm = {gamma[4 * lr], gamma[4 * lr + 1], gamma[4 * lr + 2], gamma[4 * lr + 3]};   // parameters may sit at any 4-byte offset
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  auto rsum = [](float v) {                                               // over the LPR lanes of one row
 #pragma unroll
-  for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; gm[t] = c < D ? gamma[c] : 0.f; ag[t] = 0.f; ab[t] = 0.f; }
-  auto wsum = [](float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
   };
-  for (long long r = wave; r < rows; r += nwave) {
-    float x[PER], g[PER];
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; x[t] = c < D ? s[r * D + c] : 0.f; g[t] = c < D ? dy[r * D + c] : 0.f; sum += x[t]; }
-    const float mean = wsum(sum) * (1.f / D);
-    float var = 0.f;
-#pragma unroll
-    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; const float d = c < D ? x[t] - mean : 0.f; var += d * d; }
-    const float rstd = rsqrtf(wsum(var) * (1.f / D) + 1e-5f);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-      const int c = lane + 64 * t;
-      x[t] = c < D ? (x[t] - mean) * rstd : 0.f;                          // xhat
-      ag[t] += g[t] * x[t]; ab[t] += g[t];
-      g[t] *= gm[t];                                                     // dxhat
-      s1 += g[t]; s2 += g[t] * x[t];
-    }
-    s1 = wsum(s1) * (1.f / D); s2 = wsum(s2) * (1.f / D);
-#pragma unroll
-    for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; if (c < D) ds[r * D + c] = rstd * (g[t] - s1 - x[t] * s2); }
+  for (long long r0 = wave * RPW; r0 < rows; r0 += nwave * RPW) {
+    const long long r = r0 + rw;
+    const bool ok = r < rows;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f}, g = x;
+    if (ok) { x = *reinterpret_cast<const f32x4*>(s + r * D + 4 * lr); g = *reinterpret_cast<const f32x4*>(dy + r * D + 4 * lr); }
+    const float mean = rsum(x[0] + x[1] + x[2] + x[3]) * (1.f / D);
+    x -= mean;
+    const float rstd = rsqrtf(rsum(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]) * (1.f / D) + 1e-5f);
+    x *= rstd;                                                            // xhat
+    ag += g * x; ab += g;
+    g *= gm;                                                              // dxhat
+    const float s1 = rsum(g[0] + g[1] + g[2] + g[3]) * (1.f / D);
+    const float s2 = rsum(g[0] * x[0] + g[1] * x[1] + g[2] * x[2] + g[3] * x[3]) * (1.f / D);
+    if (ok) *reinterpret_cast<f32x4*>(ds + r * D + 4 * lr) = rstd * (g - s1 - x * s2);
   }
 #pragma unroll
-  for (int t = 0; t < PER; ++t) { const int c = lane + 64 * t; if (c < D) { atomicAdd(dgamma + c, ag[t]); atomicAdd(dbeta + c, ab[t]); } }
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ag[k] += __shfl_xor(ag[k], o); ab[k] += __shfl_xor(ab[k], o); }
+  const int wv = threadIdx.x >> 6;
+  if (rw == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s_g[wv][4 * lr + k] = ag[k]; s_b[wv][4 * lr + k] = ab[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    pg[(size_t)blockIdx.x * D + c] = (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]);
+    pb[(size_t)blockIdx.x * D + c] = (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -307,6 +337,7 @@ __global__ void __launch_bounds__(256) k_vb_grad(const float* __restrict__ tr, c
 // of v_mfma_f32_32x32x2_f32 (true fp32).  For that instruction lane l supplies A[m = l % 32][k = l / 32] and B[k = l / 32][n = l % 32]:
 // with m = output feature, n = input feature and k = two consecutive rows, both operands are plain coalesced row reads from HBM
 // (no LDS, no transposes).  Stage 2 sums the slices' partial results in slice order (deterministic).
+#define WG_U 8                                                            // row pairs per software-pipeline stage
 template <int IN, int OUT, int WI, int WJ>
 __global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ part,
                                                        float* __restrict__ bpart, long long R, int rows_per_wg) {
@@ -327,19 +358,34 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__
   for (int tj = 0; tj < TJ; ++tj) bs[tj] = 0.f;
   const float* xp = X + (wi * TI) * 32 + l32;
   const float* yp = dY + (wj * TJ) * 32 + l32;
-#pragma unroll 4
-  for (long long r = r0; r < r1; r += 2) {
-    const long long rr = r + lh;
-    const bool ok = rr < r1;
-    float a[TJ], bb[TI];
+  float a[2][WG_U][TJ], bb[2][WG_U][TI];
+  auto load = [&](int buf, long long r) {
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) { a[tj] = ok ? yp[rr * OUT + tj * 32] : 0.f; bs[tj] += a[tj]; }
+    for (int u = 0; u < WG_U; ++u) {
+      const long long rr = r + 2 * u + lh;
+      const bool ok = rr < r1;
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) bb[ti] = ok ? xp[rr * IN + ti * 32] : 0.f;
+      for (int tj = 0; tj < TJ; ++tj) a[buf][u][tj] = ok ? yp[rr * OUT + tj * 32] : 0.f;
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
+      for (int ti = 0; ti < TI; ++ti) bb[buf][u][ti] = ok ? xp[rr * IN + ti * 32] : 0.f;
+    }
+  };
+  auto compute = [&](int buf) {
 #pragma unroll
-      for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tj], bb[ti], acc[tj][ti], 0, 0, 0);
+    for (int u = 0; u < WG_U; ++u)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        bs[tj] += a[buf][u][tj];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][tj], bb[buf][u][ti], acc[tj][ti], 0, 0, 0);
+      }
+  };
+  load(0, r0);
+  for (long long r = r0; r < r1; r += 4 * WG_U) {                         // two stages per trip: the loads of one run under the MFMAs of the other
+    load(1, r + 2 * WG_U);
+    compute(0);
+    load(0, r + 4 * WG_U);
+    compute(1);
   }
   float* pw = part + (size_t)blockIdx.x * OUT * IN;
 #pragma unroll
@@ -359,18 +405,25 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__
     }
   }
 }
+// Fold of the G partial results (bias columns appended: partial g = nW weights then, in a second array, nB biases): workgroup = 32
+// outputs x 8 slice groups; a thread sums its group's partials in slice order, the 8 groups are then added in group order (LDS).
 __global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dW,
                                                     float* __restrict__ db, int G, int nW, int nB) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nW) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(size_t)g * nW + t];
-    dW[t] = s;
-  } else if (t < nW + nB && db) {
-    const int c = t - nW;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += bpart[(size_t)g * nB + c];
-    db[c] = s;
+  __shared__ float s_p[8][32];
+  const int ol = threadIdx.x & 31, gg = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + ol;
+  const int per = (G + 7) / 8, g0 = gg * per, g1 = min(G, g0 + per);
+  const bool isW = t < nW, isB = !isW && t < nW + nB && db != nullptr;
+  const float* src = isW ? part + t : bpart + (t - nW);
+  const size_t stride = isW ? (size_t)nW : (size_t)nB;
+  float sum = 0.f;
+  if (isW || isB)
+    for (int g = g0; g < g1; ++g) sum += src[(size_t)g * stride];
+  s_p[gg][ol] = sum;
+  __syncthreads();
+  if (gg == 0 && (isW || isB)) {
+    for (int k = 1; k < 8; ++k) sum += s_p[k][ol];
+    if (isW) dW[t] = sum; else db[t - nW] = sum;
   }
 }
 #define WGRAD_MAX_SLICES 512
@@ -382,7 +435,7 @@ static void launch_wgrad(const float* X, const float* dY, float* dW, float* db, 
   const int G = (int)((R + per - 1) / per);
   float* bpart = ws + (size_t)G * OUT * IN;
   k_wgrad_partial<IN, OUT, WI, WJ><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
-  k_wgrad_fold<<<(IN * OUT + OUT + 255) / 256, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
+  k_wgrad_fold<<<(IN * OUT + OUT + 31) / 32, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -440,28 +493,45 @@ int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float
   const size_t nb = sizeof(float) * (size_t)B * n * dx, yb = sizeof(float) * (size_t)B * dx;
   if (hipMemsetAsync(dK, 0, nb, s) != hipSuccess || hipMemsetAsync(dV, 0, nb, s) != hipSuccess || hipMemsetAsync(dye1, 0, yb, s) != hipSuccess ||
       hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) { da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP; }
-  k_attn_bwd<<<dim3((n + ATT_IB - 1) / ATT_IB, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV,
-                                                                       dE1, dE2, dye1, dye2, n, dx);
+  const int cw = dx < 256 ? ((dx + 63) / 64) * 64 : 256;
+  static int variant = -1;                                                // DA_ATTN_BWD=<rows per block><key slices>, e.g. 42 (tuning only)
+  if (variant < 0) { const char* e = getenv("DA_ATTN_BWD"); variant = e ? atoi(e) : 42; }
+#define ATT_LAUNCH(IB_, JS_)                                                                                                      \
+  k_attn_bwd<IB_, JS_><<<dim3((n + IB_ - 1) / IB_, B), cw * JS_, sizeof(float) * JS_ * (IB_ + 2) * cw, s>>>(                       \
+      Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV, dE1, dE2, dye1, dye2, n, dx)
+  switch (variant) {
+    case 11: ATT_LAUNCH(1, 1); break;  case 12: ATT_LAUNCH(1, 2); break;  case 21: ATT_LAUNCH(2, 1); break;  case 22: ATT_LAUNCH(2, 2); break;
+    case 24: ATT_LAUNCH(2, 4); break;  case 41: ATT_LAUNCH(4, 1); break;  case 44: ATT_LAUNCH(4, 4); break;  case 82: ATT_LAUNCH(8, 2); break;
+    case 84: ATT_LAUNCH(8, 4); break;  default: ATT_LAUNCH(4, 2); break;
+  }
+#undef ATT_LAUNCH
   DA_CHECK_LAUNCH("da_attn_core_bwd");
   return DA_OK;
 }
 
-int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, long long rows, int D,
-                     void* stream) {
+#define LN_BWD_MAX_WG 1024
+int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, void* workspace,
+                     long long workspace_bytes, long long rows, int D, void* stream) {
   DA_CHECK_ARG(rows >= 0, "da_layernorm_bwd: rows");
+  DA_CHECK_ARG((((uintptr_t)s | (uintptr_t)dy | (uintptr_t)ds) & 15) == 0, "da_layernorm_bwd: s, dy, ds must be 16-byte aligned");
+  DA_CHECK_ARG(workspace && workspace_bytes >= (long long)sizeof(float) * 2 * LN_BWD_MAX_WG * D, "da_layernorm_bwd: workspace needs 8 * 1024 * D bytes");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * D, st) != hipSuccess) {
-    da_set_error("da_layernorm_bwd: memset failed"); return DA_ERR_HIP;
+  if (rows == 0) {
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * D, st) != hipSuccess) {
+      da_set_error("da_layernorm_bwd: memset failed"); return DA_ERR_HIP;
+    }
+    return DA_OK;
   }
-  if (rows == 0) return DA_OK;
-  long long g = (rows + 3) / 4; if (g > 2048) g = 2048;
+  long long g = (rows * D / 256 + 3) / 4; if (g < 1) g = 1; if (g > LN_BWD_MAX_WG) g = LN_BWD_MAX_WG;   // a wave pass covers 256 floats
+  float* pg = (float*)workspace; float* pb = pg + (size_t)g * D;
   switch (D) {
-    case 32: k_ln_bwd<32><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
-    case 64: k_ln_bwd<64><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
-    case 128: k_ln_bwd<128><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
-    case 256: k_ln_bwd<256><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, dgamma, dbeta, rows); break;
+    case 32: k_ln_bwd<32><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, pg, pb, rows); break;
+    case 64: k_ln_bwd<64><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, pg, pb, rows); break;
+    case 128: k_ln_bwd<128><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, pg, pb, rows); break;
+    case 256: k_ln_bwd<256><<<(unsigned)g, 256, 0, st>>>(s, gamma, dy, ds, pg, pb, rows); break;
     default: da_set_error("da_layernorm_bwd: width %d not built (32, 64, 128, 256)", D); return DA_ERR_UNSUPPORTED;
   }
+  k_wgrad_fold<<<(2 * D + 31) / 32, 256, 0, st>>>(pg, pb, dgamma, dbeta, (int)g, D, D);
   DA_CHECK_LAUNCH("da_layernorm_bwd");
   return DA_OK;
 }

@@ -110,6 +110,7 @@ class TrainingMixin:
         optimizer.zero_grad()
         _, _, loss = self.training_step(data, i, t_int=t_int, noise=noise, z_t=z_t)
         loss.backward()
+        optimizer.gather()
         world = distributed.allreduce_flat_gradient(optimizer.flat_grad, group=group)
         optimizer.step(grad_scale=1.0 / world)
         return loss.detach()

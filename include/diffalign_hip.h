@@ -155,9 +155,10 @@ long long da_linear_wgrad_workspace(long long R, int in_features, int out_featur
 int da_linear_wgrad(const float* X, const float* dY, float* dW, float* db, void* workspace, long long workspace_bytes, long long R,
                     int in_features, int out_features, void* stream);
 /* LayerNorm backward (eps 1e-5; layers.py:341-359): s (rows,D) = the normalised input, dy the gradient of gamma * xhat + beta ->
- * ds (rows,D), dgamma (D), dbeta (D).  D in {32, 64, 128, 256}. */
-int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, long long rows, int D,
-                     void* stream);
+ * ds (rows,D), dgamma (D), dbeta (D).  D in {32, 64, 128, 256}; s, dy, ds 16-byte aligned; workspace: 8 * 1024 * D bytes for the
+ * per-workgroup partial sums of dgamma / dbeta (folded in workgroup order: deterministic). */
+int da_layernorm_bwd(const float* s, const float* gamma, const float* dy, float* ds, float* dgamma, float* dbeta, void* workspace,
+                     long long workspace_bytes, long long rows, int D, void* stream);
 /* Xtoy / Etoy pooled statistics (layers.py:15-47) of T (B,N,d): z (B,4,d) = [mean, min, max, unbiased std] over the N rows, arg
  * (B,2,d) int32 = row index of the min / max (first occurrence); and the backward dT from dz.  workspace: room for the per-slice
  * partial results, 32 * B * 64 * d bytes covers every N (NULL / too small: one workgroup column per graph, slow for N = n*n). */

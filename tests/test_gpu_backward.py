@@ -82,8 +82,9 @@ def test_add_layernorm_backward(Dw):
 def test_layernorm_backward_rejects_unbuilt_width():
     from diffalign_amd import _lib as L
     s = torch.randn(4, 48, device=D)
+    ws = torch.empty(8 * 1024 * 48, dtype=torch.uint8, device=D)
     rc = L.lib().da_layernorm_bwd(L.ptr(s), L.ptr(torch.ones(48, device=D)), L.ptr(s), L.ptr(torch.empty_like(s)), L.ptr(torch.empty(48, device=D)),
-                                  L.ptr(torch.empty(48, device=D)), 4, 48, L.stream())
+                                  L.ptr(torch.empty(48, device=D)), L.ptr(ws), ws.numel(), 4, 48, L.stream())
     assert rc != 0 and 'width 48' in L.last_error()
 
 
@@ -281,7 +282,9 @@ def test_fused_adamw_matches_torch():
         for r, m in zip(ref, mine):
             gr = torch.randn(r.shape, generator=g) * (10.0 if step == 1 else 1.0)     # a spike, so that amsgrad's running max matters
             r.grad = gr.clone()
-            m.grad.add_(gr.to(D))                                                     # accumulate into the flat views, as autograd does
+            m.grad = gr.to(D)                                                         # what backward() leaves
+        o.gather()
+        assert all(m.grad.data_ptr() >= o.flat_grad.data_ptr() for m in mine)         # .grad now views the flat buffer
         o_ref.step(); o.step()
     for r, m in zip(ref, mine):
         assert (m.detach().cpu() - r.detach()).abs().max() <= 1e-6
