@@ -228,9 +228,9 @@ def main():
         t = state['t']
         t_arr = torch.full((B, 1), t, dtype=torch.long, device=dev)
         z_t.y = t_arr.float() * 5
-        pred = model.forward(z_t, pos_encodings=pos)
-        _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_arr), tm.get_Qt_bar(t_arr - 1),
-                                                  tm.get_Qt_bar(t_arr), orig=data, node_masks=masks, generator=gen)
+        # what sample_one_batch runs per step: denoiser forward with the edge half of posterior / draw / apply_mask drawn inside its
+        # output kernel (per-chain counter noise, seeds from `gen`), the node half behind the node output path
+        zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, generator=gen)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
 

@@ -73,7 +73,7 @@ SIGNATURES = {
     'da_align_index': 'i:pppiip',
     'da_x_out_finish': 'i:pipipppiiip',
     'da_edge_out': 'i:ppipppppiiiiip',
-    'da_edge_out_tiles': 'i:ppipppppiiiiip',
+    'da_edge_out_tiles': 'i:ppipppppiiiiip', 'da_edge_out_sample': 'i:ppipppppppppfppqpppiiiiip',
     'da_edge_out_g': 'i:pppiiiip',
     'da_edge_out_finish': 'i:ppippppiiip',
     'da_extra_adjacency': 'i:pppppppiiip',

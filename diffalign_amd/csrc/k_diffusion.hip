@@ -2,6 +2,7 @@
 // draw + apply_mask (fused), forward noising.  All HBM-bound integer/float elementwise work.
 // Reference semantics: see include/diffalign_hip.h for the file:line each entry point replaces.
 #include "common.h"
+#include "diffusion_dev.h"
 
 #define MAXK 32   // max number of classes handled in registers
 
@@ -147,22 +148,6 @@ __device__ __forceinline__ void posterior_elem(const float* __restrict__ logit, 
   for (int k = 0; k < K; ++k) u[k] = u[k] / tot;
 }
 
-template <int K>
-__device__ __forceinline__ int onehot_argmax(const float* x) {
-  int best = 0; float bv = x[0];
-#pragma unroll
-  for (int k = 1; k < K; ++k) if (x[k] > bv) { bv = x[k]; best = k; }
-  return best;
-}
-// exponential race: argmax_k p[k] / q[k], first index wins ties (torch.multinomial on CPU)
-template <int K>
-__device__ __forceinline__ int race(const float* p, const float* q) {
-  int best = 0; float bv = p[0] / q[0];
-#pragma unroll
-  for (int k = 1; k < K; ++k) { float v = p[k] / q[k]; if (v > bv) { bv = v; best = k; } }
-  return best;
-}
-
 // nodes: one thread per (b,i)
 template <int K>
 __global__ void k_posterior_X(const float* logits, const float* zt, const uint8_t* nm, const float* Qt, const float* Qsb,
@@ -246,47 +231,6 @@ __global__ void k_posterior_E(const float* logits, const float* zt, const uint8_
   }
 }
 
-// posterior_elem with the per-(xt, k0, k) factor (Qt[k][xt] * Qsb[k0][k]) / d[k0] taken from a table M[xt][k0][k] that was
-// filled with exactly that expression: same operations on the same values in the same order => same bits.
-template <int K>
-__device__ __forceinline__ void posterior_elem_tab(const float* __restrict__ logit, int xt, const float* M, float temp, float* u) {
-  float l[K];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) { l[k] = logit[k]; mx = fmaxf(mx, l[k]); }
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) s += expf(l[k] - mx);
-  float lse = mx + logf(s);
-  float mx2 = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) { l[k] = (l[k] - lse) * temp; mx2 = fmaxf(mx2, l[k]); }
-  float s2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) { l[k] = expf(l[k] - mx2); s2 += l[k]; }
-#pragma unroll
-  for (int k = 0; k < K; ++k) u[k] = 0.f;
-  const float* Mx = M + xt * K * K;
-#pragma unroll
-  for (int k0 = 0; k0 < K; ++k0) {
-    float ph = l[k0] / s2;
-#pragma unroll
-    for (int k = 0; k < K; ++k) u[k] += ph * Mx[k0 * K + k];
-  }
-  float tot = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) tot += u[k];
-  if (tot == 0.f) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) u[k] = 1e-5f;
-    tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) tot += u[k];
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k) u[k] = u[k] / tot;
-}
-
 // edges, draw only (no probabilities out): one workgroup per pair of mirrored 32x32 tiles (it <= jt).  Each unordered pair is
 // evaluated ONCE, by its upper-triangle element; the class goes through LDS to both output tiles, which are written
 // row-wise.  Same arithmetic per element as k_posterior_E (bit-identical draws), half the evaluations, no transposed reads.
@@ -301,15 +245,7 @@ __global__ void __launch_bounds__(256) k_posterior_E_tiles(const float* __restri
   const int b = blockIdx.y;
   __shared__ float sM[K * K * K];
   __shared__ uint8_t cls[32][33];
-  {
-    const float* qt = Qt + (size_t)b * K * K; const float* qsb = Qsb + (size_t)b * K * K; const float* qtb = Qtb + (size_t)b * K * K;
-    for (int t = threadIdx.x; t < K * K * K; t += 256) {
-      const int xt = t / (K * K), k0 = (t / K) % K, k = t % K;
-      float d = qtb[k0 * K + xt];
-      if (d == 0.f) d = 1e-6f;
-      sM[t] = (qt[k * K + xt] * qsb[k0 * K + k]) / d;
-    }
-  }
+  posterior_table_fill<K>(Qt + (size_t)b * K * K, Qsb + (size_t)b * K * K, Qtb + (size_t)b * K * K, sM, threadIdx.x, 256);
   __syncthreads();
   const size_t base = (size_t)b * n * n;
   for (int t = threadIdx.x; t < 32 * 32; t += 256) {

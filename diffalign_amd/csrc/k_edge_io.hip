@@ -3,6 +3,7 @@
 // LDS, one wave per query row (b,i), 32-pair tiles; both orientations (i,j) and (j,i) are evaluated by the same wave
 // so the symmetrisation needs no second pass over the edge tensor.
 #include "mfma_util.h"
+#include "diffusion_dev.h"
 
 template <int DE, int HE>
 struct EdgeIoCfg {
@@ -429,12 +430,25 @@ __global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict
 //   phase 3  tile (jt, it) written row-wise from LDS (+ its own skip term); skipped on diagonal tiles
 // Every hidden edge row is read once, row-wise, and no intermediate reaches HBM.  Same arithmetic per element as
 // k_edge_out / k_edge_out_finish (a + b == b + a): bit-identical logits.
+// SAMPLE (da_edge_out_sample, Ke == 7): the reverse step's edge half replaces the logits output.  Phase 2 leaves the finished
+// logits of tile (it, jt) (skip term included) in LDS instead of HBM; then every thread takes upper-triangle pairs (i < j) of the
+// tile, evaluates the posterior over the 7x7 tables (posterior_elem_tab: k_posterior_E_tiles' arithmetic, same bits) and draws the
+// class by the exponential race, from an explicit noise tensor or from the chain's counter-based noise (counter_exp: the values of
+// da_counter_exp_noise, never materialised); the classes go through LDS to both mirrored tiles of z_s (one-hot fp32, or the
+// condition's row where the pair is not free).  No logits, no phase 3.  (A first form that drew inside phase 2, on the half-wave
+// that holds a row's pairs, needed 162 registers -- one workgroup per CU instead of two -- and ran 720 us against 339 + 237.)
 constexpr int OT_NW = 8, OT_THR = 64 * OT_NW;   // waves / threads per workgroup of k_edge_out_tiles (4 and 16 measured: slower)
-template <int DE, int HE>
-__global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
+constexpr int OT_K = 7;                         // edge classes of the fused reverse step
+struct OutSampleArgs {
+  const float* zt; const uint8_t* nm; const float* Qt; const float* Qsb; const float* Qtb; float temp;
+  const float* noise; const int64_t* seeds; unsigned long long stream;
+  const float* orig; const uint8_t* me; float* zs;
+};
+template <int DE, int HE, bool SAMPLE>
+__global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
                                                         const uint4* __restrict__ blob, const int* __restrict__ src,
                                                         const float* __restrict__ s1p, const float* __restrict__ s2p,
-                                                        float* __restrict__ E_o, int n, int Ke) {
+                                                        float* __restrict__ E_o, int n, int Ke, OutSampleArgs sa) {
   using C = EdgeIoCfg<DE, HE>;
   int it, jt;
   tri_tile(blockIdx.x, (n + 31) / 32, it, jt);
@@ -456,6 +470,18 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
   if (threadIdx.x < 64) {
     const int w = threadIdx.x >> 5, q = (w ? jt : it) * 32 + (threadIdx.x & 31);
     sSrc[w][threadIdx.x & 31] = (src && q < n) ? src[gb + q] : -1;
+  }
+  __shared__ float sM[SAMPLE ? OT_K * OT_K * OT_K : 1];  // posterior factor table of this graph
+  __shared__ uint8_t sCls[SAMPLE ? 32 : 1][33];          // drawn class of pair (row i, column j) of tile (it, jt), i < j
+  __shared__ uint8_t sNm[2][32], sFree[2][32];           // node mask / free-to-diffuse flag of the tile's rows i ([0]) and j ([1])
+  if constexpr (SAMPLE) {
+    posterior_table_fill<OT_K>(sa.Qt + (size_t)b * OT_K * OT_K, sa.Qsb + (size_t)b * OT_K * OT_K, sa.Qtb + (size_t)b * OT_K * OT_K, sM,
+                               threadIdx.x, OT_THR);
+    if (threadIdx.x < 64) {
+      const int w = threadIdx.x >> 5, q = (w ? jt : it) * 32 + (threadIdx.x & 31);
+      sNm[w][threadIdx.x & 31] = q < n ? sa.nm[gb + q] : 0;
+      sFree[w][threadIdx.x & 31] = (q < n && sa.me) ? sa.me[gb + q] : 1;
+    }
   }
   uint4 cur[DE / 16], nxt[DE / 16];
   float ein_c[4], ein_n[4];                             // E_in[row, pair, 4h .. 4h+3] of the current / next row
@@ -517,9 +543,10 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
         if (c >= Ke) continue;
         float* m = sB + (r * 32 + ri) * 8 + c;          // (G + E_in)[b, j, i]
         float v = (jA == i) ? 0.f : 0.5f * ((o[e] + ein_c[e]) + *m);
-        *m = v;
+        if constexpr (!SAMPLE) *m = v;
         if (src) v += aligned ? s1 * aln_c[e] : (c == 0 ? s2 : 0.f);
-        srow[r * Ke + c] = v;                           // the row's 32 * Ke logits, contiguous as in memory
+        if constexpr (SAMPLE) *m = v;                   // the finished logit of pair (i, j) stays in LDS for the draw
+        else srow[r * Ke + c] = v;                      // the row's 32 * Ke logits, contiguous as in memory
       }
     }
 #pragma unroll
@@ -527,13 +554,60 @@ __global__ void __launch_bounds__(OT_THR) k_edge_out_tiles(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ein_c[e] = ein_n[e]; aln_c[e] = aln_n[e]; }
     // one coalesced store of the row from the wave's LDS staging (same-wave LDS traffic is ordered: no barrier)
-    const int cnt = min(32, n - jt * 32) * Ke;
-    float* drow = E_o + ((gb + i) * n + jt * 32) * Ke;
-    if (vec4 && (cnt & 3) == 0) {
-      if (lane * 4 < cnt) *reinterpret_cast<float4*>(drow + lane * 4) = *reinterpret_cast<const float4*>(srow + lane * 4);
-    } else {
-      for (int t = lane; t < cnt; t += 64) drow[t] = srow[t];
+    if constexpr (!SAMPLE) {
+      const int cnt = min(32, n - jt * 32) * Ke;
+      float* drow = E_o + ((gb + i) * n + jt * 32) * Ke;
+      if (vec4 && (cnt & 3) == 0) {
+        if (lane * 4 < cnt) *reinterpret_cast<float4*>(drow + lane * 4) = *reinterpret_cast<const float4*>(srow + lane * 4);
+      } else {
+        for (int t = lane; t < cnt; t += 64) drow[t] = srow[t];
+      }
     }
+  }
+  if constexpr (SAMPLE) {
+    __syncthreads();                                      // the tile's logits are complete in sB ([column j][row i][8])
+    const size_t base = (size_t)b * n * n;
+    for (int t = threadIdx.x; t < 32 * 32; t += OT_THR) { // pair (row ri, column cj): k_posterior_E_tiles' evaluation of it
+      const int ri = t >> 5, cj = t & 31, i = it * 32 + ri, j = jt * 32 + cj;
+      int c = 0;
+      if (i < j && j < n && sNm[0][ri] && sNm[1][cj]) {
+        const size_t pr = base + (size_t)i * n + j;
+        float lg[OT_K], u[OT_K], q[OT_K];
+        const float* lp = sB + (cj * 32 + ri) * 8;
+#pragma unroll
+        for (int k = 0; k < OT_K; ++k) lg[k] = lp[k];
+        const int xt = onehot_argmax<OT_K>(sa.zt + pr * OT_K);
+        posterior_elem_tab<OT_K>(lg, xt, sM, sa.temp, u);
+        if (sa.noise) {
+#pragma unroll
+          for (int k = 0; k < OT_K; ++k) q[k] = sa.noise[pr * OT_K + k];
+        } else {
+          const unsigned long long seed = (unsigned long long)sa.seeds[b], e0 = ((unsigned long long)i * n + j) * OT_K;
+#pragma unroll
+          for (int k = 0; k < OT_K; ++k) q[k] = counter_exp(seed, sa.stream, e0 + k);
+        }
+        c = race<OT_K>(u, q);
+      }
+      sCls[ri][cj] = (uint8_t)c;
+    }
+    __syncthreads();
+    constexpr int W = 32 * OT_K;
+    for (int t = threadIdx.x; t < 32 * W; t += OT_THR) {  // tile (it, jt), rows i
+      const int ri = t / W, o = t - ri * W, cj = o / OT_K, k = o - cj * OT_K, i = it * 32 + ri, j = jt * 32 + cj;
+      if (i >= n || j >= n) continue;
+      const int c = i < j ? sCls[ri][cj] : (i > j ? sCls[cj][ri] : 0);   // i > j only inside a diagonal tile
+      const size_t q = (base + (size_t)i * n + j) * OT_K + k;
+      sa.zs[q] = (sFree[0][ri] && sFree[1][cj]) ? (k == c ? 1.f : 0.f) : sa.orig[q];
+    }
+    if (jt != it)
+      for (int t = threadIdx.x; t < 32 * W; t += OT_THR) { // tile (jt, it), rows j
+        const int rj = t / W, o = t - rj * W, ci = o / OT_K, k = o - ci * OT_K, j = jt * 32 + rj, i = it * 32 + ci;
+        if (i >= n || j >= n) continue;
+        const int c = sCls[ci][rj];
+        const size_t q = (base + (size_t)j * n + i) * OT_K + k;
+        sa.zs[q] = (sFree[0][ci] && sFree[1][rj]) ? (k == c ? 1.f : 0.f) : sa.orig[q];
+      }
+    return;
   }
   if (jt == it) return;
   __syncthreads();
@@ -710,13 +784,42 @@ int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void*
   const int nt = (n + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   if (de == 64 && he == 128)
-    k_edge_out_tiles<64, 128><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
-        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
+    k_edge_out_tiles<64, 128, false><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke, OutSampleArgs{});
   else if (de == 32 && he == 32)
-    k_edge_out_tiles<32, 32><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
-        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke);
+    k_edge_out_tiles<32, 32, false><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, E_logits, n, ke, OutSampleArgs{});
   else { da_set_error("da_edge_out_tiles: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_out_tiles");
+  return DA_OK;
+}
+
+// Output stage + the edge half of the reverse step in one kernel (sampling.py:82-86,165-178 behind transformer_model_with_y.py:
+// 672-704): z_s E (B,n,n,7) one-hot fp32 drawn from p(z_s | z_t) of the logits this stage produces, with apply_mask folded in, exactly
+// as da_edge_out_tiles followed by da_posterior_sample's edge half (draw-only form) gives -- same logits, same posterior arithmetic,
+// same race: bit-identical z_s for the same noise.  Noise: noise_E (B,n,n,7) Exp(1) (upper triangle read), or NULL with chain_seeds (B)
+// and `call`: the values da_counter_exp_noise(chain_seeds, call) would put there, generated in registers.  The logits are not written.
+int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1, const float* skip2,
+                       const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
+                       float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
+                       float* zs_E, int B, int n, int de, int he, int ke, void* stream) {
+  DA_CHECK_ARG(ke == OT_K && ke <= de_in, "da_edge_out_sample: built for %d edge classes (got %d, input width %d)", OT_K, ke, de_in);
+  DA_CHECK_ARG(!(src && (!skip1 || !skip2)), "da_edge_out_sample: skip connection needs both scale pointers");
+  DA_CHECK_ARG(zt_E && node_mask && Qt_e && Qsb_e && Qtb_e && zs_E, "da_edge_out_sample: null pointer");
+  DA_CHECK_ARG(noise_E || (chain_seeds && call >= 0), "da_edge_out_sample: needs noise_E or chain_seeds + call");
+  DA_CHECK_ARG(!mask_e || orig_E, "da_edge_out_sample: a free mask needs the condition's E");
+  if (B == 0 || n == 0) return DA_OK;
+  const int nt = (n + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  OutSampleArgs sa{zt_E, node_mask, Qt_e, Qsb_e, Qtb_e, temp_e, noise_E, chain_seeds, 2ull * (unsigned long long)call + 1ull, orig_E, mask_e, zs_E};
+  if (de == 64 && he == 128)
+    k_edge_out_tiles<64, 128, true><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, nullptr, n, ke, sa);
+  else if (de == 32 && he == 32)
+    k_edge_out_tiles<32, 32, true><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<32, 32>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
+        (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, nullptr, n, ke, sa);
+  else { da_set_error("da_edge_out_sample: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  DA_CHECK_LAUNCH("da_edge_out_sample");
   return DA_OK;
 }
 

@@ -5,6 +5,7 @@
 //                    sampling run independent of the rank layout (diffalign_amd/distributed.py)
 // All HBM-bound scatter / fill kernels; nothing here is on the per-layer path.
 #include "common.h"
+#include "diffusion_dev.h"
 
 // ptr[b] = first row of graph b in the sorted batch vector, ptr[B] = N
 __global__ void k_batch_ptr(const int64_t* __restrict__ batch, long long N, int B, int64_t* __restrict__ ptr) {
@@ -74,17 +75,6 @@ __global__ void k_inpaint(const int* __restrict__ nodes, int Nn, const int* __re
   }
 }
 
-// 24 random bits of (seed, stream, element) -> u in (0,1) -> Exp(1).  splitmix64's finaliser over a Weyl-stepped key; the same
-// integers as oracle.counter_exp_noise (numpy uint64).
-__device__ __forceinline__ float counter_exp(unsigned long long seed, unsigned long long stream, unsigned long long elem) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (stream + 1ull);
-  z ^= elem * 0xD1B54A32D192ED03ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float u = ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
-  return -__logf(u);
-}
 __global__ void k_counter_exp_noise(const int64_t* __restrict__ seeds, unsigned long long stream, float* __restrict__ out, long long per_chain,
                                     long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

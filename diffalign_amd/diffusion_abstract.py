@@ -131,9 +131,31 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                            node_mask=noisy_data.node_mask, atom_map_numbers=noisy_data.atom_map_numbers,
                            mol_assignments=noisy_data.mol_assignments)
 
-    def forward(self, z_t, use_pos_encoding_if_applicable=None, pos_encodings=None):
+    def reverse_step(self, z_t, t_array, pos_encodings=None, transition_model=None, temperature=(1.0, 1.0), noise=None, chain_seeds=None,
+                     call=0, orig=None, node_masks=None, generator=None, want_logits=False):
+        """One reverse step p(z_s | z_t) (diffusion/sampling.py:76-86,165-178): denoiser forward + posterior + categorical draw +
+        apply_mask.  With 7 edge classes the edge half is drawn inside the denoiser's output kernel (da_edge_out_sample; the
+        (B,n,n,7) logits and noise tensors never reach HBM); otherwise forward() + helpers.posterior_sample.  Both give the same
+        z_s for the same noise, bit for bit.  Returns (zs_X, zs_E, pred); pred.E is None in the fused form (want_logits=True: separate form)."""
+        from . import helpers
+        tm = transition_model if transition_model is not None else self.transition_model_eval
+        Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
+        if self.model.supports_fused_step() and not self.model._differentiable() and not want_logits:
+            ctx = helpers.reverse_step_ctx(z_t, Qt, Qsb, Qtb, temperature, noise, chain_seeds, call, orig, node_masks, generator)
+            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings, step=ctx)
+            return ctx['zs_X'], ctx['zs_E'], pred
+        B, n, kx = z_t.X.shape
+        if noise is None and chain_seeds is not None:
+            noise = helpers.counter_exp_noise(chain_seeds.to(z_t.X.device), call, B, n, kx, z_t.E.shape[-1])
+        pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)
+        _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, Qt, Qsb, Qtb, temperature=temperature, noise=noise, orig=orig,
+                                                  node_masks=node_masks, generator=generator)
+        return zsX, zsE, pred
+
+    def forward(self, z_t, use_pos_encoding_if_applicable=None, pos_encodings=None, step=None):
         """diffusion_abstract.py:293-348 (denoiser='neuralnet').  The reference's random relabelling of atom-map
-        numbers (:297-300) is output-invariant and is skipped (it only consumes RNG and a host sync)."""
+        numbers (:297-300) is output-invariant and is skipped (it only consumes RNG and a host sync).
+        `step`: helpers.reverse_step_ctx(...) -- the reverse step fused behind the output stage (see reverse_step)."""
         if self.cfg.diffusion.denoiser != 'neuralnet':
             raise NotImplementedError("only denoiser='neuralnet' is built")
         z_in = self.compute_extra_data(z_t) if self.cfg.neuralnet.extra_features else z_t
@@ -144,8 +166,8 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
             if use_pos_encoding_if_applicable is not None:
                 pos_encodings = pos_encodings * use_pos_encoding_if_applicable[:, None, None].float()
             X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask, z_in.atom_map_numbers, pos_encodings,
-                                            z_in.mol_assignments)
+                                            z_in.mol_assignments, **({'step': step} if step is not None else {}))
         else:
-            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask)
+            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask, **({'step': step} if step is not None else {}))
         return PlaceHolder(X=X, E=E, y=y, node_mask=node_mask, atom_map_numbers=z_t.atom_map_numbers,
                            mol_assignments=z_t.mol_assignments)

@@ -16,6 +16,7 @@ N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
 N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
 STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
+FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
 SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
 SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
@@ -249,9 +250,11 @@ def _side_stream(dev):
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
-                  use_skip=False, save: Optional[dict] = None):
+                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None):
     """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
-    `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py)."""
+    `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py).
+    `step`: the reverse step fused behind the output stage (helpers.ReverseStep.ctx: z_t, transition tables, noise, masks): the edge
+    half is drawn inside the output kernel (da_edge_out_sample) and the edge logits are not materialised (Eo is None); the node half runs behind the node output path.  The drawn state lands in step['zs_X'], step['zs_E']."""
     dev = X.device
     B, n = X.shape[:2]
     R = B * n
@@ -365,6 +368,13 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         _linear(h1, pm.hx, pm.out_X[2], pm.out_X[3], None, lin, pm.kx, R, pm.kx, pm.hx, False)
         L.check(lib.da_x_out_finish(L.ptr(lin), _i(pm.kx), L.ptr(X), _i(pm.dx_in), L.ptr(src), L.ptr(s1), L.ptr(Xo), _i(B), _i(n),
                                     _i(pm.kx), L.stream()), 'da_x_out_finish')
+        if step is not None:                         # node half of the reverse step (posterior + draw + apply_mask), latency-bound
+            c = step
+            N_ = L.ptr(None)
+            L.check(lib.da_posterior_sample(L.ptr(Xo), N_, L.ptr(c['zt_X']), N_, L.ptr(nm), L.ptr(c['Qt_x']), L.ptr(c['Qsb_x']), L.ptr(c['Qtb_x']),
+                                            N_, N_, N_, C.c_float(c['temp'][0]), C.c_float(c['temp'][1]), L.ptr(c['noise_X']), N_,
+                                            L.ptr(c['orig_X']), N_, L.ptr(c['mx']), N_, N_, N_, L.ptr(c['zs_X']), N_, _i(B), _i(n), _i(pm.kx),
+                                            _i(pm.ke), L.stream()), 'da_posterior_sample')
 
     xout_done = None
     if side2 is None:
@@ -375,8 +385,15 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             side2.wait_event(xh_ready)
             node_output_path()
             xout_done = side2.record_event()
-    Eo = torch.empty(B, n, n, pm.ke, device=dev)
-    if EDGE_OUT == 'tiles':
+    Eo = torch.empty(B, n, n, pm.ke, device=dev) if step is None else None
+    if step is not None:
+        c = step
+        L.check(lib.da_edge_out_sample(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2),
+                                       L.ptr(c['zt_E']), L.ptr(nm), L.ptr(c['Qt_e']), L.ptr(c['Qsb_e']), L.ptr(c['Qtb_e']),
+                                       C.c_float(c['temp'][1]), L.ptr(c['noise_E']), L.ptr(c['seeds']),
+                                       int(c['call']), L.ptr(c['orig_E']), L.ptr(c['me']), L.ptr(c['zs_E']), _i(B), _i(n), _i(pm.de), _i(pm.he),
+                                       _i(pm.ke), S), 'da_edge_out_sample')
+    elif EDGE_OUT == 'tiles':
         L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo),
                                       _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')
     elif EDGE_OUT == '2pass':

@@ -82,6 +82,38 @@ def posterior_sample(pred_X, pred_E, z_t: PlaceHolder, Qt: PlaceHolder, Qsb: Pla
     return probX, probE, zsX, zsE
 
 
+def reverse_step_ctx(z_t: PlaceHolder, Qt: PlaceHolder, Qsb: PlaceHolder, Qtb: PlaceHolder, temperature=(1.0, 1.0),
+                     noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, chain_seeds: Optional[torch.Tensor] = None, call: int = 0,
+                     orig: Optional[PlaceHolder] = None, node_masks=None, generator=None) -> dict:
+    """What engine.model_forward(step=...) needs to draw z_s behind the denoiser's output stage (the fused form of posterior_sample).
+    Noise, in this order of preference: explicit Exp(1) tensors `noise` = (qX, qE); per-chain counter noise (`chain_seeds`, `call`:
+    the edge half generates da_counter_exp_noise's values in registers, never materialising the (B,n,n,ke) tensor); otherwise
+    per-chain seeds are drawn from torch's generator and used the same way."""
+    B, n, kx = z_t.X.shape
+    ke = z_t.E.shape[-1]
+    dev = z_t.X.device
+    f = lambda t: t.contiguous().float()
+    qX = qE = seeds = None
+    if noise is not None:
+        qX, qE = f(noise[0]), f(noise[1])
+    else:
+        if chain_seeds is None:
+            chain_seeds = torch.randint(0, 2 ** 62, (B,), device=dev, generator=generator)
+            call = 0
+        seeds = chain_seeds.to(device=dev, dtype=torch.int64).contiguous()
+        qX = torch.empty(B, n, kx, device=dev)
+        L.check(L.lib().da_counter_exp_noise(L.ptr(seeds, torch.int64), int(call), L.ptr(qX), L.ptr(None), B, n, kx, ke, L.stream()),
+                'da_counter_exp_noise')
+    oX = oE = mx = me = None
+    if node_masks is not None:
+        assert orig is not None
+        oX, oE = f(orig.X), f(orig.E)
+        mx, me = L.as_u8(node_masks[0]), L.as_u8(node_masks[1])
+    return dict(zt_X=f(z_t.X), zt_E=f(z_t.E), Qt_x=f(Qt.X), Qsb_x=f(Qsb.X), Qtb_x=f(Qtb.X), Qt_e=f(Qt.E), Qsb_e=f(Qsb.E), Qtb_e=f(Qtb.E),
+                temp=(float(temperature[0]), float(temperature[1])), noise_X=qX, noise_E=qE, seeds=seeds, call=int(call),
+                orig_X=oX, orig_E=oE, mx=mx, me=me, zs_X=torch.empty(B, n, kx, device=dev), zs_E=torch.empty(B, n, n, ke, device=dev))
+
+
 def get_p_zs_given_zt(transition_model, t_array, pred, z_t, return_prob=False, temperature_scaling=1.0, noise=None):
     """helpers.py:193-245.  `pred` holds logits (the caller may have applied log_softmax*temperature already, as
     diffusion/sampling.py:82 does: softmax is idempotent on log-probabilities)."""

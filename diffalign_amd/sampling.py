@@ -34,10 +34,16 @@ class SamplingMixin:
             assert noise_fn is None and chain_seeds.shape == (B,)
             chain_seeds = chain_seeds.to(device=device, dtype=torch.int64)
 
-        def nz():
+        def nz(step=False):
+            """Noise of the next draw.  step=True (the reverse steps): keyword arguments for reverse_step -- with chain seeds the
+            (B,n,n,ke) noise tensor is never materialised (the fused kernel generates the same values in registers)."""
             if chain_seeds is not None:
                 calls[0] += 1
+                if step:
+                    return dict(chain_seeds=chain_seeds, call=calls[0] - 1)
                 return helpers.counter_exp_noise(chain_seeds, calls[0] - 1, B, n, kx, ke)
+            if step:
+                return dict(noise=nz())
             if noise_fn is None:
                 return None
             qx = noise_fn(calls[0], (B * n, kx)).reshape(B, n, kx).to(device)
@@ -73,9 +79,16 @@ class SamplingMixin:
         for t_int in range(T_eval, 0, -1):
             t_array = torch.full((B, 1), t_int, dtype=torch.long, device=device)
             z_t.y = t_array.float() * eval_step_size                       # raw train-scale step index (sampling.py:76)
-            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)
             s_int = t_int - 1
-            if get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1):       # sampling.py:120-161 (plotting chains)
+            record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)
+            if not record:                                                 # the whole step as one call (fused where the model allows)
+                zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
+                                                orig=dense_data, node_masks=masks, **nz(step=True))
+                z_t.X, z_t.E = zsX, zsE
+                z_t = fix(z_t)
+                continue
+            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)
+            if record:                                                                   # sampling.py:120-161 (plotting chains)
                 sample_chains.append((t_int, z_t.get_new_object().mask(z_t.node_mask, collapse=True)))
                 p0 = pred.get_new_object(X=torch.softmax(pred.X, -1), E=torch.softmax(pred.E, -1))
                 p0.X[..., -1] = 0.                                         # SuNo predictions ignored (sampling.py:125-126)

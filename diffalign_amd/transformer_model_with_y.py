@@ -48,6 +48,10 @@ class _DenoiserBase(nn.Module):
         """train() mode with autograd on: the fp32 training forward (train_forward.py) instead of the fused bf16 inference path."""
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
+    def supports_fused_step(self):
+        """da_edge_out_sample (the reverse step's edge half inside the output kernel) is built for 7 edge classes."""
+        return self.out_dim_E == 7 and engine.EDGE_OUT == 'tiles' and engine.FUSED_STEP
+
     def _check(self, X):
         if not X.is_cuda:
             raise L.DiffAlignHipError('denoiser inputs must be on a HIP device (no CPU fallback)')
@@ -59,13 +63,13 @@ class GraphTransformerWithY(_DenoiserBase):
         super().__init__()
         self._build(n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in, act_fn_out, improved, dropout)
 
-    def forward(self, X, E, y, node_mask):
+    def forward(self, X, E, y, node_mask, step=None):
         self._check(X)
         if self._differentiable():
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask) + (node_mask,)
         pm = self._pack(X.device)
-        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, save=self._saved)
+        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, save=self._saved, step=step)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask
 
@@ -89,7 +93,7 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
             self.skip_scaling_2 = nn.Parameter(torch.tensor([p_to_r_init], dtype=torch.float))
             self.skip_scaling_3 = nn.Parameter(torch.tensor([1.], dtype=torch.float))
 
-    def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments):
+    def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments, step=None):
         assert atom_map_numbers is not None
         self._check(X)
         if self._differentiable():
@@ -97,6 +101,6 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
             return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
-                                          use_skip=self.p_to_r_skip_connection, save=self._saved)
+                                          use_skip=self.p_to_r_skip_connection, save=self._saved, step=step)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask

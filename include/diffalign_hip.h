@@ -316,6 +316,16 @@ int da_edge_out(const void* E_h, const float* E_in, int de_in, const void* blob,
  * its partner in LDS; no scratch).  Same arguments, bit-identical logits. */
 int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
                       const float* skip2, float* E_logits, int B, int n, int de, int he, int ke, void* stream);
+/* Output stage + the edge half of the reverse step in one kernel (diffusion/sampling.py:82-86,165-178 behind
+ * neuralnet/transformer_model_with_y.py:672-704; utils/diffusion/helpers.py:193-245,706-752; utils/graph.py:411-534 apply_mask):
+ * zs_E (B,n,n,7) one-hot fp32 drawn from p(z_s | z_t) of the logits this stage computes, apply_mask folded in -- bit-identical to
+ * da_edge_out_tiles followed by da_posterior_sample's edge half for the same noise, without the (B,n,n,7) logits round trip.
+ * Noise: noise_E (B,n,n,7) Exp(1), or NULL with chain_seeds (B) + call: the values da_counter_exp_noise(chain_seeds, call) would
+ * write, generated in registers.  The logits are not written (callers that want them use the separate form).  ke must be 7. */
+int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1, const float* skip2,
+                       const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
+                       float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
+                       float* zs_E, int B, int n, int de, int he, int ke, void* stream);
 /* The same output stage in two passes, each hidden edge row read once and mlp_out_E evaluated once per ordered pair
  * (da_edge_out evaluates both orientations in one pass and reads the hidden tensor twice): G (B,n,n,8) fp32 is a scratch
  * the caller owns.  da_edge_out_g: G = mlp_out_E(E_h) (transformer_model_with_y.py:672-673); da_edge_out_finish:

@@ -1,0 +1,112 @@
+"""GPU: the fused reverse step (da_edge_out_sample: posterior + draw + apply_mask of the edge half inside the denoiser's output
+kernel; DiscreteDenoisingDiffusion.reverse_step) against the separate form (forward -> da_edge_out_tiles logits ->
+da_posterior_sample).  Integer work on identical logits: the bar is bit-exact z_s, for explicit noise tensors and for the
+in-register counter noise, on the tiny golden model (32-wide kernels) and at align_absorbing widths (64/128-wide kernels)."""
+import pytest
+import torch
+
+from tests.golden.common import ATOMS, BONDS
+from tests.test_gpu_elbo import setup, KX, KE, D
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(model, data, z_t, t, pos, masks, **noise_kw):
+    from diffalign_amd import helpers
+    tm = model.transition_model_eval
+    zsX, zsE, pred_f = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                                          **noise_kw)
+    assert model.model.supports_fused_step() and pred_f.E is None                      # fused: the edge logits never reach HBM
+    pred = model.forward(z_t=z_t, pos_encodings=pos)
+    B, n = z_t.X.shape[:2]
+    if 'noise' in noise_kw:
+        noise = noise_kw['noise']
+    else:
+        noise = helpers.counter_exp_noise(noise_kw['chain_seeds'].to(D), noise_kw['call'], B, n, KX, KE)
+    _, _, rX, rE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t), tm.get_Qt_bar(t - 1), tm.get_Qt_bar(t), temperature=(1.0, 0.9),
+                                            noise=noise, orig=data, node_masks=masks)
+    assert torch.equal(pred_f.X, pred.X)
+    assert torch.equal(zsX, rX), int((zsX != rX).sum())
+    assert torch.equal(zsE, rE), int((zsE != rE).any(-1).sum())
+    assert torch.equal(zsE, zsE.transpose(1, 2))                                       # mirrored draws
+    # want_logits: the separate form through the same call
+    zsX2, zsE2, pred_n = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                                            want_logits=True, **noise_kw)
+    assert torch.equal(pred_n.E, pred.E) and torch.equal(zsX2, rX) and torch.equal(zsE2, rE)
+    return rX, rE
+
+
+def test_fused_step_tiny_model_explicit_and_counter_noise():
+    from diffalign_amd import graph, helpers
+    z, model, data, pos = setup()
+    B, n = data.X.shape[:2]
+    masks = graph.get_node_masks(data, list(ATOMS), list(BONDS), 'product_and_sn', 'product_and_sn')
+    g = torch.Generator(device=D).manual_seed(3)
+    for t_int in (10, 4, 1):
+        t = torch.full((B, 1), t_int, dtype=torch.long, device=D)
+        z_t, _ = model.apply_noise(data, t_int=t.float(), transition_model=model.transition_model_eval,
+                                   noise=(helpers.exp_noise_like((B, n, KX), D, g), helpers.exp_noise_like((B, n, n, KE), D, g)))
+        z_t = graph.apply_mask(orig=data, z_t=z_t, atom_decoder=list(ATOMS), bond_decoder=list(BONDS), node_masks=masks)
+        z_t.y = t.float()
+        qX, qE = helpers.exp_noise_like((B, n, KX), D, g), helpers.exp_noise_like((B, n, n, KE), D, g)
+        rX, rE = _both(model, data, z_t, t, pos, masks, noise=(qX, qE))
+        assert rE.argmax(-1).unique().numel() > 1                                      # the draws are not trivially constant
+        seeds = torch.tensor([11, 2 ** 40 + 5, 7, 123456789], dtype=torch.int64)
+        _both(model, data, z_t, t, pos, masks, chain_seeds=seeds, call=3 + t_int)
+
+
+def test_fused_step_full_widths_ragged():
+    from bench import FULL, make_cfg, make_info
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import graph, synthetic as S
+    torch.manual_seed(1)
+    dims = dict(FULL, n_layers=2)
+    model = DiscreteDenoisingDiffusion(make_cfg(dims), make_info(), device=D).eval()
+    B, n = 5, 75                                                                        # 3 x 3 tiles, the last ones partial
+    true = S.make_reaction_batch(B, n, seed=4, P=None)
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    pos = S.shared_pos_encodings(true, 256, seed=3).to(D)
+    model.pos_encodings_fn = lambda z: pos
+    masks = graph.get_node_masks(data, model.dataset_info.atom_decoder, model.dataset_info.bond_decoder, 'product_and_sn', 'product_and_sn')
+    zt0 = S.noised_state(true, t=40, T=100, abs_x=S.IDX_AU, seed=9)
+    z_t = data.get_new_object(X=zt0['X'].to(D), E=zt0['E'].to(D), y=zt0['y'].to(D))
+    t = torch.full((B, 1), 40, dtype=torch.long, device=D)
+    with torch.no_grad():
+        rX, rE = _both(model, data, z_t, t, pos, masks, chain_seeds=torch.arange(B, dtype=torch.int64) * 977 + 1, call=17)
+        # not-free pairs keep the condition, free pairs are one-hot
+        me = masks[1].bool()
+        free = me[:, :, None] & me[:, None, :]
+        assert torch.equal(rE[~free], data.E[~free]) and torch.all(rE[free].sum(-1) == 1)
+
+
+def test_sampling_loop_uses_the_fused_step_and_matches_the_separate_chain():
+    """sample_one_batch with explicit noise: the loop (fused steps) reproduces, bit for bit, a hand-written loop of forward +
+    posterior_sample on the same noise."""
+    from diffalign_amd import graph, helpers
+    from tests.golden.common import counter_noise
+    z, model, data, pos = setup()
+    B, n = data.X.shape[:2]
+    noise_fn = lambda c, shp: counter_noise(shp, 900 + c)
+    with torch.no_grad():
+        got = model.sample_one_batch(data=data, noise_fn=noise_fn)
+        masks = graph.get_node_masks(data, list(ATOMS), list(BONDS), 'product_and_sn', 'product_and_sn')
+        calls = [0]
+
+        def nz():
+            qx = noise_fn(calls[0], (B * n, KX)).reshape(B, n, KX).to(D); qe = noise_fn(calls[0] + 1, (B * n * n, KE)).reshape(B, n, n, KE).to(D)
+            calls[0] += 2
+            return qx, qe
+        z_t = helpers.sample_from_noise(limit_dist=model.limit_dist, node_mask=data.node_mask, T=model.T, noise=nz())
+        z_t = data.get_new_object(X=z_t.X, E=z_t.E, y=z_t.y)
+        z_t = graph.apply_mask(orig=data, z_t=z_t, atom_decoder=list(ATOMS), bond_decoder=list(BONDS), node_masks=masks)
+        tm = model.transition_model_eval
+        T_eval = model.cfg.diffusion.diffusion_steps_eval
+        for t_int in range(T_eval, 0, -1):
+            t = torch.full((B, 1), t_int, dtype=torch.long, device=D)
+            z_t.y = t.float() * (model.T // T_eval)
+            pred = model.forward(z_t=z_t, pos_encodings=model.get_pos_encodings_if_relevant(data))
+            _, _, zX, zE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t), tm.get_Qt_bar(t - 1), tm.get_Qt_bar(t),
+                                                    temperature=(1.0, 1.0), noise=nz(), orig=data, node_masks=masks)
+            z_t.X, z_t.E = zX, zE
+    assert torch.equal(got.X, z_t.X) and torch.equal(got.E, z_t.E)
