@@ -69,7 +69,7 @@ SIGNATURES = {
     'da_edge_split_scratch_bytes': 'q:iii',
     'da_edge_stats': 'i:ppiiiip',
     'da_x_stats': 'i:ppiiiip',
-    'da_y_update': 'i:pppppiiiiiiiip',
+    'da_y_update': 'i:pppppiiiiiiiip', 'da_y_pre': 'i:pppiiiiip', 'da_y_update_film': 'i:ppppppppppiiiiiiip',
     'da_align_index': 'i:pppiip',
     'da_x_out_finish': 'i:pipipppiiip',
     'da_edge_out': 'i:ppipppppiiiiip',

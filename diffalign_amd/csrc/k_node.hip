@@ -276,12 +276,8 @@ struct YFilmArgs {
 };
 // FiLM vectors of one layer (layers.py:245-247,268-270); the additive edge FiLM is folded through e_out:
 //   e_out(ye1 + (ye2+1)*Y) = e_out.W((ye2+1)*Y) + [e_out.b + e_out.W ye1]
-__global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
-  extern __shared__ float sm[];
-  float* v = sm; float* ye1 = sm + a.dy;
-  const int b = blockIdx.x;
-  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v[k] = a.y[(size_t)b * a.dy + k];
-  __syncthreads();
+// v: y of graph b in LDS (dy floats); ye1: dx floats of LDS followed by blockDim.x floats of scratch
+__device__ __forceinline__ void y_film_body(const YFilmArgs& a, const float* v, float* ye1, int b) {
   block_matvec(a.We_add, a.dy, a.be_add, v, ye1, a.dx, a.dy, false);
   block_matvec(a.We_mul, a.dy, a.be_mul, v, a.ye2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
   block_matvec(a.Wx_add, a.dy, a.bx_add, v, a.yx1 + (size_t)b * a.dx, a.dx, a.dy, false);
@@ -289,7 +285,14 @@ __global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
   __syncthreads();
   block_matvec_T(a.Wout, a.bout, ye1, a.ebias + (size_t)b * a.de, ye1 + a.dx, a.de, a.dx, false);   // Wout = e_out.weight^T (dx,de)
 }
-
+__global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
+  extern __shared__ float sm[];
+  float* v = sm; float* ye1 = sm + a.dy;
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v[k] = a.y[(size_t)b * a.dy + k];
+  __syncthreads();
+  y_film_body(a, v, ye1, b);
+}
 struct YUpdArgs {
   const float* y; const float* xstats; const float* estats;   // partials (B,nchunk,4,d): sum, sum of squares, min, max
   const float *WxyT, *bxy, *WeyT, *bey;               // x_y.lin^T (4dx,dy), e_y.lin^T (4de,dy)
@@ -297,6 +300,7 @@ struct YUpdArgs {
   const float *n1g, *n1b, *W1, *b1, *W2T, *b2, *n2g, *n2b;   // norm_y1, lin_y1 (dff,dy), lin_y2^T (dff,dy), norm_y2
   float* out;
   int n, dx, de, dy, dff, nchunk_x, nchunk_e;
+  const float* xy;                                    // (B,dy) x_y.lin(Xtoy statistics) precomputed by k_y_pre, or NULL: computed here
 };
 // chunk partials -> (mean, min, max, unbiased std) per channel in dst[4*d].  Threads = (channel, chunk slice): every slice
 // folds its chunks with independent loads, the slices meet in LDS `scr` (>= 4 * blockDim.x floats).  Ends synchronised.
@@ -327,8 +331,9 @@ __device__ __forceinline__ void pooled_stats(const float* part, int nchunk, int 
 }
 // new_y = y_out(y + Xtoy(X) + Etoy(E)); y = LN(y+new_y); y = LN(y + lin_y2(relu(lin_y1(y))))
 // (layers.py:15-47,277-281,346-359).  Statistics run over ALL n nodes / n^2 pairs (padding included), std unbiased.
-__global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
-  extern __shared__ float sm[];
+// `film`: NULL, or the NEXT layer's FiLM arguments -- its vectors are then produced here from the new y while it is still in LDS
+// (one launch and one dependent kernel start less on the chain between two edge kernels).
+__device__ __forceinline__ void y_update_body(const YUpdArgs& a, const YFilmArgs* film, float* sm) {
   float* sx = sm;                       // 4*dx
   float* se = sx + 4 * a.dx;            // 4*de
   float* v0 = se + 4 * a.de;            // dy
@@ -337,11 +342,12 @@ __global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
   float* hb = v2 + a.dy;                // dff
   float* scr = hb + a.dff;              // 4 * blockDim.x
   const int b = blockIdx.x, n = a.n;
-  pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx, scr);
+  if (a.xy == nullptr) pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx, scr);
   pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se, scr);
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v0[k] = a.y[(size_t)b * a.dy + k];
   __syncthreads();
-  block_matvec_T(a.WxyT, a.bxy, sx, v1, scr, a.dy, 4 * a.dx, false);
+  if (a.xy == nullptr) block_matvec_T(a.WxyT, a.bxy, sx, v1, scr, a.dy, 4 * a.dx, false);
+  else for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] = a.xy[(size_t)b * a.dy + k];
   __syncthreads();
   block_matvec_T(a.WeyT, a.bey, se, v2, scr, a.dy, 4 * a.de, false);
   __syncthreads();
@@ -360,7 +366,27 @@ __global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
   __syncthreads();
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
   __syncthreads();
-  block_layernorm(v1, a.n2g, a.n2b, a.out + (size_t)b * a.dy, a.dy);
+  block_layernorm(v1, a.n2g, a.n2b, v2, a.dy);       // v2 = the layer's output y (LDS)
+  for (int k = threadIdx.x; k < a.dy; k += blockDim.x) a.out[(size_t)b * a.dy + k] = v2[k];
+  if (film != nullptr) y_film_body(*film, v2, sx, b); // sx .. : dx floats + blockDim.x floats of scratch (4 dx + 4 de + ... >= dx + 1024)
+}
+__global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
+  extern __shared__ float sm[];
+  y_update_body(a, nullptr, sm);
+}
+__global__ void __launch_bounds__(1024) k_y_update_film(YUpdArgs a, YFilmArgs f) {
+  extern __shared__ float sm[];
+  y_update_body(a, &f, sm);
+}
+// The part of y_update that does not depend on the edge kernel: x_y.lin of the Xtoy statistics of the layer's input X -> xy (B,dy).
+// Launched beside q/k/v, off the chain between two edge kernels (its 4 dx -> dy contraction is the largest of the y branch).
+__global__ void __launch_bounds__(1024) k_y_pre(const float* xstats, const float* WxyT, const float* bxy, float* xy, int n, int dx, int dy,
+                                                int nchunk_x) {
+  extern __shared__ float sm[];
+  float* sx = sm; float* scr = sx + 4 * dx;
+  const int b = blockIdx.x;
+  pooled_stats(xstats + (size_t)b * nchunk_x * 4 * dx, nchunk_x, dx, (double)n, sx, scr);
+  block_matvec_T(WxyT, bxy, sx, xy + (size_t)b * dy, scr, dy, 4 * dx, false);
 }
 
 // pooled statistics partials of X (Xtoy, layers.py:15-29): out[b][chunk][4][D] over the chunk's rows (padding included)
@@ -482,10 +508,44 @@ int da_y_update(const float* y, const float* xstats, const float* estats,
   DA_CHECK_ARG(dy > 0 && 1024 % dy == 0, "da_y_update: dy=%d must divide 1024", dy);
   if (B == 0) return DA_OK;
   YUpdArgs a{y, xstats, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
-             w[14], w[15], out, n, dx, de, dy, dff, nchunk_x, nchunk_e};
+             w[14], w[15], out, n, dx, de, dy, dff, nchunk_x, nchunk_e, nullptr};
   size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 4 * 1024) * sizeof(float);
   k_y_update<<<B, 1024, sh, (hipStream_t)stream>>>(a);
   DA_CHECK_LAUNCH("da_y_update");
+  return DA_OK;
+}
+
+// x_y.lin(Xtoy statistics) of a layer's input X (layers.py:15-29, 277): xy (B,dy) from the chunk partials da_x_stats wrote.  The part
+// of da_y_update that does not depend on the layer's edge kernel; w_upd: da_y_update's pointer array (WxyT, bxy are its first two).
+int da_y_pre(const float* xstats, const float* const* w_upd, float* xy, int B, int n, int dx, int dy, int nchunk_x, void* stream) {
+  DA_CHECK_ARG(dy > 0 && 1024 % dy == 0 && 1024 % dx == 0, "da_y_pre: dy=%d and dx=%d must divide 1024", dy, dx);
+  if (B == 0) return DA_OK;
+  k_y_pre<<<B, 1024, (size_t)(4 * dx + 4 * 1024) * sizeof(float), (hipStream_t)stream>>>(xstats, w_upd[0], w_upd[1], xy, n, dx, dy, nchunk_x);
+  DA_CHECK_LAUNCH("da_y_pre");
+  return DA_OK;
+}
+
+// da_y_update with the Xtoy term given (xy from da_y_pre; same values, same bits as computing it here) and, when film_w is not NULL,
+// da_y_film of the NEXT layer appended to the same launch (layers.py:241-262 of layer l+1 behind :277-281,346-359 of layer l).
+int da_y_update_film(const float* y, const float* xy, const float* estats, const float* const* w_upd, float* out,
+                     const float* const* film_w /* 10 pointers, YFilmArgs order, or NULL */, float* ye2p1, float* ebias, float* yx1,
+                     float* yx2p1, int B, int n, int dx, int de, int dy, int dff, int nchunk_e, void* stream) {
+  DA_CHECK_ARG(dy > 0 && 1024 % dy == 0 && de > 0 && 1024 % de == 0, "da_y_update_film: dy=%d and de=%d must divide 1024", dy, de);
+  DA_CHECK_ARG(xy && estats && out, "da_y_update_film: null pointer");
+  if (B == 0) return DA_OK;
+  const float* const* w = w_upd;
+  YUpdArgs a{y, nullptr, estats, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13],
+             w[14], w[15], out, n, dx, de, dy, dff, 0, nchunk_e, xy};
+  size_t sh = (size_t)(4 * dx + 4 * de + 3 * dy + dff + 4 * 1024) * sizeof(float);
+  if (film_w) {
+    DA_CHECK_ARG(ye2p1 && ebias && yx1 && yx2p1, "da_y_update_film: FiLM outputs");
+    const float* const* fw = film_w;
+    YFilmArgs f{nullptr, fw[0], fw[1], fw[2], fw[3], fw[4], fw[5], fw[6], fw[7], fw[8], fw[9], ye2p1, ebias, yx1, yx2p1, dy, dx, de};
+    k_y_update_film<<<B, 1024, sh, (hipStream_t)stream>>>(a, f);
+  } else {
+    k_y_update<<<B, 1024, sh, (hipStream_t)stream>>>(a);
+  }
+  DA_CHECK_LAUNCH("da_y_update_film");
   return DA_OK;
 }
 

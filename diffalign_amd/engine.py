@@ -16,6 +16,7 @@ N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
 N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
 STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
+Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
 FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
 SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
@@ -135,39 +136,38 @@ def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de):
     return st
 
 
-def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None, stats_out=None):
-    """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
-    fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
-    `film`: the FiLM vectors if the caller computed them already (layer_film); `before_edge` / `after_edge`: hooks called
-    right before / after the edge kernel is enqueued (stream joins of the pipelined y branch); `stats_out`: buffer
-    (B, N_TAIL_CHUNKS, 4, de) that receives the Etoy statistics partials of E_bf16 from the edge kernel's tail."""
-    dev = X.device
-    dx, de, dy = pm.dx, pm.de, pm.dy
-    R = B * n
-    lib = L.lib()
-    S = L.stream()
-    ye2p1, ebias, yx1, yx2p1 = film if film is not None else layer_film(pm, lw, y, B, film_buffers(pm, B, dev))
-    kvf = torch.empty(lib.da_kv_frag_bytes(_i(B), _i(n), _i(dx)), dtype=torch.uint8, device=dev)
+def _qkv(pm: PackedModel, lw: dict, X, nm_u8, B, n, out=None):
+    """q, k, v projections of a layer: Q (R, ldq) fp32 and K, V as the edge kernel's bf16 fragments.  `out`: preallocated (Qm, kvf)."""
+    dev, dx, R, lib, S = X.device, pm.dx, B * n, L.lib(), L.stream()
+    Qm, kvf = out if out is not None else _qkv_buffers(pm, B, n, dev)
     if pm.fused_qkv:
-        Qm = torch.empty(R, dx, device=dev); ldq = dx
         L.check(lib.da_qkv_frag(L.ptr(X), L.ptr(lw['Wqkv']), L.ptr(lw['bqkv']), L.ptr(nm_u8), L.ptr(Qm), L.ptr(kvf), _i(B), _i(n),
                                 _i(dx), S), 'da_qkv_frag')
     else:
-        Qm = torch.empty(R, 3 * dx, device=dev); ldq = 3 * dx
         _linear(X, dx, lw['Wqkv'], lw['bqkv'], nm_u8, Qm, 3 * dx, R, 3 * dx, dx, False)
         fsz = 4
         L.check(lib.da_kv_pack(C.c_void_p(Qm.data_ptr() + dx * fsz), C.c_void_p(Qm.data_ptr() + 2 * dx * fsz), _i(3 * dx),
                                L.ptr(kvf), _i(B), _i(n), _i(dx), S), 'da_kv_pack')
+    return Qm, kvf
+
+
+def _qkv_buffers(pm: PackedModel, B, n, dev):
+    kvf = torch.empty(L.lib().da_kv_frag_bytes(_i(B), _i(n), _i(pm.dx)), dtype=torch.uint8, device=dev)
+    return torch.empty(B * n, pm.dx if pm.fused_qkv else 3 * pm.dx, device=dev), kvf
+
+
+def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None):
+    """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out."""
+    dev, dx, de, lib, S = E_bf16.device, pm.dx, pm.de, L.lib(), L.stream()
+    ye2p1, ebias, yx1, yx2p1 = film
     E_out = torch.empty_like(E_bf16)
     nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
-    newX_in = torch.empty(R, dx, device=dev)
+    newX_in = torch.empty(B * n, dx, device=dev)
     ticket = pm.ticket if stats_out is not None else None
-    if before_edge is not None:
-        before_edge()
     if PROFILE_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
-    args = (L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(ldq), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
+    args = (L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(Qm.shape[1]), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
             L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
             C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
             L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
@@ -177,9 +177,13 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
     if PROFILE_EVENTS is not None:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
-    if after_edge is not None:
-        after_edge()
-    X2 = torch.empty(B, n, dx, device=dev)
+    return E_out, newX_in, split
+
+
+def _x_post(pm: PackedModel, lw: dict, newX_in, X, nm_u8, B, n, out=None):
+    """Node tail of a layer (layers.py:266-273, 340-351): x_out + mask, normX1, FFN X, normX2."""
+    dev, dx, R, lib, S = X.device, pm.dx, B * n, L.lib(), L.stream()
+    X2 = out if out is not None else torch.empty(B, n, dx, device=dev)
     if lw['xpost'] is not None:
         L.check(lib.da_x_post(L.ptr(newX_in), L.ptr(X), L.ptr(nm_u8), L.ptr(lw['xpost']), L.ptr(X2), _i(R), _i(dx), _i(pm.dffx), S),
                 'da_x_post')
@@ -195,7 +199,23 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
         _linear(hbuf, pm.dffx, lw['W2'], lw['b2'], None, ff, dx, R, dx, pm.dffx, False)
         L.check(lib.da_add_layernorm(L.ptr(X1), L.ptr(ff), L.ptr(lw['n2'][0]), L.ptr(lw['n2'][1]), L.ptr(X2), _i(R), _i(dx), S),
                 'da_add_layernorm')
-    return X2, E_out
+    return X2
+
+
+def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, before_edge=None, after_edge=None, stats_out=None):
+    """X and E branches of one XEyTransformerLayer (neuralnet/layers.py:204-273, 330-351): FiLM vectors from y, q/k/v, the
+    fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
+    `film`: the FiLM vectors if the caller computed them already (layer_film); `before_edge` / `after_edge`: hooks called
+    right before / after the edge kernel is enqueued (stream joins of the pipelined y branch); `stats_out`: buffer
+    (B, N_TAIL_CHUNKS, 4, de) that receives the Etoy statistics partials of E_bf16 from the edge kernel's tail."""
+    film = film if film is not None else layer_film(pm, lw, y, B, film_buffers(pm, B, X.device))
+    Qm, kvf = _qkv(pm, lw, X, nm_u8, B, n)
+    if before_edge is not None:
+        before_edge()
+    E_out, newX_in, _ = _edge(pm, lw, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out)
+    if after_edge is not None:
+        after_edge()
+    return _x_post(pm, lw, newX_in, X, nm_u8, B, n), E_out
 
 
 def node_stats(pm: PackedModel, X, B, n, out=None):
@@ -207,6 +227,21 @@ def node_stats(pm: PackedModel, X, B, n, out=None):
 def y_update(pm: PackedModel, lw: dict, y, xst, estats, B, n, out):
     L.check(L.lib().da_y_update(L.ptr(y), L.ptr(xst), L.ptr(estats), lw['yup'].arr, L.ptr(out), _i(B), _i(n), _i(pm.dx),
                                 _i(pm.de), _i(pm.dy), _i(pm.dffy), _i(N_XSTAT_CHUNKS), _i(estats.shape[1]), L.stream()), 'da_y_update')
+    return out
+
+
+def y_pre(pm: PackedModel, lw: dict, xst, B, n, out):
+    """x_y.lin(Xtoy statistics): the part of y_update that needs only the layer's input X (C-ABI da_y_pre)."""
+    L.check(L.lib().da_y_pre(L.ptr(xst), lw['yup'].arr, L.ptr(out), _i(B), _i(n), _i(pm.dx), _i(pm.dy), _i(N_XSTAT_CHUNKS), L.stream()), 'da_y_pre')
+    return out
+
+
+def y_update_film(pm: PackedModel, lw: dict, nxt: Optional[dict], y, xy, estats, B, n, out, film_out):
+    """y_update of layer `lw` from the precomputed Xtoy term, with the FiLM vectors of the next layer in the same launch."""
+    f = film_out if nxt is not None else (None, None, None, None)
+    L.check(L.lib().da_y_update_film(L.ptr(y), L.ptr(xy), L.ptr(estats), lw['yup'].arr, L.ptr(out), nxt['film'].arr if nxt is not None else None,
+                                     L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(f[3]), _i(B), _i(n), _i(pm.dx), _i(pm.de), _i(pm.dy),
+                                     _i(pm.dffy), _i(estats.shape[1]), L.stream()), 'da_y_update_film')
     return out
 
 
@@ -247,6 +282,71 @@ def _side_stream(dev):
     if key not in _SIDE:
         _SIDE[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
     return _SIDE[key]
+
+
+def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2):
+    """The layer stack with three streams.  Between two edge kernels two chains run: the y branch (y_update(l) needs the Etoy
+    statistics the edge kernel of layer l leaves, then the FiLM vectors of layer l+1: ~100 us, 64 small workgroups) and the node chain
+    (merge, node tail of layer l, q/k/v of layer l+1: ~80 us).  The LONGER one, the y branch, stays on the caller's stream right
+    behind the edge kernel and in front of the next one, so that it never waits for a cross-stream event (each costs 15-30 us of
+    idle GPU when it is on the critical path); the node chain runs on a side stream, the Xtoy statistics of the next layer on a
+    third.  Every buffer is allocated on the caller's stream and stays referenced until that stream has joined its last reader."""
+    dev = Xh.device
+    ev_x = None                                      # q/k/v of the coming layer complete (side stream)
+    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
+    xy = torch.empty(B, pm.dy, device=dev)
+    Qm, kvf = _qkv_buffers(pm, B, n, dev)
+    x_ready = main.record_event()
+    with torch.cuda.stream(side2):                   # Xtoy statistics of layer 0's input and their x_y.lin term
+        side2.wait_event(x_ready)
+        node_stats(pm, Xh, B, n, out=xst)
+        y_pre(pm, pm.layers[0], xst, B, n, xy)
+        xs_done = side2.record_event()
+    _qkv(pm, pm.layers[0], Xh, nm, B, n, out=(Qm, kvf))
+    if y_done0 is not None:
+        main.wait_event(y_done0)                     # FiLM vectors of layer 0 (y stream of the input stage)
+    main.wait_event(xs_done)
+    keep = []
+    for li, lw in enumerate(pm.layers):
+        nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
+        tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
+        st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
+        X_next = torch.empty(B, n, pm.dx, device=dev)
+        y_next = torch.empty(B, pm.dy, device=dev)
+        film_next = film_buffers(pm, B, dev) if nxt is not None else None
+        qkv_next = _qkv_buffers(pm, B, n, dev) if nxt is not None else None
+        xst_next = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev) if nxt is not None else None
+        xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
+        if ev_x is not None:
+            main.wait_event(ev_x)
+        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail)
+        ev_edge = main.record_event()
+        with torch.cuda.stream(side):                # node chain
+            side.wait_event(ev_edge)
+            _x_post(pm, lw, newX_in, Xh, nm, B, n, out=X_next)
+            ev_xp = side.record_event()
+        if nxt is not None:
+            with torch.cuda.stream(side2):           # next layer's Xtoy statistics and their x_y.lin term beside its q/k/v
+                side2.wait_event(ev_xp)
+                node_stats(pm, X_next, B, n, out=xst_next)
+                y_pre(pm, nxt, xst_next, B, n, xy_next)
+                xs_next_done = side2.record_event()
+        with torch.cuda.stream(side):
+            if nxt is not None:
+                _qkv(pm, nxt, X_next, nm, B, n, out=qkv_next)
+                side.wait_event(xs_next_done)        # one event for the caller's stream to wait on: q/k/v and the Xtoy term
+            ev_x = side.record_event()
+        # y chain, behind the edge kernel on its own stream (xy of this layer was joined before the edge kernel through ev_x)
+        y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
+        keep.append((Xh, Eh, yh, film, Qm, kvf, xst, xy, st, newX_in, split))
+        if len(keep) > 2:
+            keep.pop(0)                              # layer l-2: main has joined the side streams of layer l-1 since
+        Xh, Eh, yh, film, xst, xy = X_next, E_next, y_next, film_next, xst_next, xy_next
+        if nxt is not None:
+            Qm, kvf = qkv_next
+    main.wait_event(ev_x)
+    del keep
+    return Xh, Eh, yh
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
@@ -321,42 +421,45 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
-        # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
-        film, y_done = film0, y_done0
-        keep = []
-        for li, lw in enumerate(pm.layers):
-            tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
-            st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
-            xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
-            x_ready = main.record_event()            # Xh is complete: its Xtoy statistics run beside q/k/v on a stream of their own
-            with torch.cuda.stream(side2):               # (on the y stream they lengthen the chain the next edge kernel waits for: +0.12 ms/step)
-                side2.wait_event(x_ready)
-                node_stats(pm, Xh, B, n, out=xst)
-                xs_done = side2.record_event()
-            nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
-            y_next = torch.empty(B, pm.dy, device=dev)
-            film_next = film_buffers(pm, B, dev) if nxt is not None else None
+        if Y_ON_MAIN:
+            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2)
+        else:
+            # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
+            film, y_done = film0, y_done0
+            keep = []
+            for li, lw in enumerate(pm.layers):
+                tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
+                st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
+                xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
+                xy = torch.empty(B, pm.dy, device=dev)
+                x_ready = main.record_event()            # Xh is complete: its Xtoy statistics run beside q/k/v on a stream of their own
+                with torch.cuda.stream(side2):               # (on the y stream they lengthen the chain the next edge kernel waits for: +0.12 ms/step)
+                    side2.wait_event(x_ready)
+                    node_stats(pm, Xh, B, n, out=xst)
+                    y_pre(pm, lw, xst, B, n, xy)         # ... and their x_y.lin term, the largest contraction of the y branch
+                    xs_done = side2.record_event()
+                nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
+                y_next = torch.empty(B, pm.dy, device=dev)
+                film_next = film_buffers(pm, B, dev) if nxt is not None else None
 
-            def join(ev=y_done):
-                if ev is not None:
-                    main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
+                def join(ev=y_done):
+                    if ev is not None:
+                        main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
 
-            def fork(lw=lw, y=yh, st=st, xst=xst, xs_done=xs_done, y_next=y_next, nxt=nxt, film_next=film_next):
-                ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    side.wait_event(xs_done)
-                    y_update(pm, lw, y, xst, st, B, n, y_next)
-                    if nxt is not None:
-                        layer_film(pm, nxt, y_next, B, film_next)
+                def fork(lw=lw, y=yh, st=st, xy=xy, xs_done=xs_done, y_next=y_next, nxt=nxt, film_next=film_next):
+                    ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
+                    with torch.cuda.stream(side):
+                        side.wait_event(xs_done)
+                        side.wait_event(ready)
+                        y_update_film(pm, lw, nxt, y, xy, st, B, n, y_next, film_next)   # y_update(l) + FiLM vectors of layer l+1: one launch
 
-            X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork, stats_out=tail)
-            y_done = side.record_event()
-            keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
-            keep.append((Xh, yh, st, xst, film))
-            Xh, Eh, yh, film = X_next, E_next, y_next, film_next
-        main.wait_event(y_done)
-        del keep
+                X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork, stats_out=tail)
+                y_done = side.record_event()
+                keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
+                keep.append((Xh, yh, st, xst, xy, film))
+                Xh, Eh, yh, film = X_next, E_next, y_next, film_next
+            main.wait_event(y_done)
+            del keep
     # ---- output stage (the node output path beside the edge output stage)
     h1 = torch.empty(R, pm.hx, device=dev)
     lin = torch.empty(R, pm.kx, device=dev)

@@ -296,6 +296,14 @@ int da_x_stats(const float* X, float* partials, int B, int n, int D, int nchunk,
  * y_out.0.{W,b}, y_out.2.{W,b}, norm_y1.{w,b}, lin_y1.{W,b}, lin_y2.W^T, lin_y2.b, norm_y2.{w,b} (^T = stored (in,out)). */
 int da_y_update(const float* y, const float* xstats, const float* estats, const float* const* w /*host*/, float* out,
                 int B, int n, int dx, int de, int dy, int dff, int nchunk_x, int nchunk_e, void* stream);
+/* The part of da_y_update that does not depend on the layer's edge kernel: xy (B,dy) = x_y.lin(Xtoy statistics of the layer's input X)
+ * (layers.py:15-29, 277) from da_x_stats' partials; w_upd = da_y_update's pointer array. */
+int da_y_pre(const float* xstats, const float* const* w_upd, float* xy, int B, int n, int dx, int dy, int nchunk_x, void* stream);
+/* da_y_update with that term given and, when film_w is not NULL, da_y_film of the NEXT layer in the same launch (layers.py:241-262 of
+ * layer l+1 behind :277-281,346-359 of layer l): two dependent launches less on the chain between two edge kernels. */
+int da_y_update_film(const float* y, const float* xy, const float* estats, const float* const* w_upd, float* out,
+                     const float* const* film_w, float* ye2p1, float* ebias, float* yx1, float* yx2p1, int B, int n, int dx, int de,
+                     int dy, int dff, int nchunk_e, void* stream);
 
 /* src[b,r] = product node carrying the same atom-map number as reactant-side node r, else -1: the gather form of
  * get_X_prods_and_E_prods_aligned + create_permutation_matrix_torch (transformer_model_with_y.py:506-555,
