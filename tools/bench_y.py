@@ -1,0 +1,47 @@
+"""GPU micro-benchmark of the y chain between two edge kernels (da_y_update_film) at the benchmark size.
+   python tools/bench_y.py [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import FULL, make_cfg, make_info
+from diffalign_amd import engine, _lib as L
+from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = 300
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+model = DiscreteDenoisingDiffusion(make_cfg(FULL), make_info(), device=dev).eval()
+pm = model.model._pack(dev)
+lw, nxt = pm.layers[0], pm.layers[1]
+y = torch.randn(B, pm.dy, device=dev); xy = torch.randn(B, pm.dy, device=dev)
+st = torch.randn(B, engine.N_TAIL_CHUNKS, 4, pm.de, device=dev).abs()
+out = torch.empty(B, pm.dy, device=dev); film = engine.film_buffers(pm, B, dev)
+xst = torch.randn(B, engine.N_XSTAT_CHUNKS, 4, pm.dx, device=dev).abs()
+
+
+def timed(name, fn, reps=50):
+    for _ in range(5): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    print(f'{name:28s} {a.elapsed_time(b) / reps * 1e3:8.1f} us', flush=True)
+
+
+print('dy', pm.dy, 'dffy', pm.dffy, 'dx', pm.dx, 'de', pm.de)
+timed('y_update_film', lambda: engine.y_update_film(pm, lw, nxt, y, xy, st, B, n, out, film))
+timed('y_update_film (no film)', lambda: engine.y_update_film(pm, lw, None, y, xy, st, B, n, out, film))
+timed('y_film', lambda: engine.layer_film(pm, nxt, y, B, film))
+timed('y_pre', lambda: engine.y_pre(pm, lw, xst, B, n, xy))
+timed('y_update (old)', lambda: engine.y_update(pm, lw, y, xst, st, B, n, out))
+
+
+def upd(dff, film_on=True):
+    f = film if film_on else (None, None, None, None)
+    L.check(L.lib().da_y_update_film(L.ptr(y), L.ptr(xy), L.ptr(st), lw['yup'].arr, L.ptr(out), nxt['film'].arr if film_on else None,
+                                     L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(f[3]), B, n, pm.dx, pm.de, pm.dy, dff, st.shape[1], L.stream()), 'x')
+
+
+for dff in (64, 512, 2048):
+    timed(f'update only, dff={dff} (timing probe)', lambda: upd(dff, False))
