@@ -45,11 +45,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if rc != 0:
                 raise RuntimeError(f'hipcc failed for {src}:\n{err}')
     objs = [os.path.join(OBJ, f[:-4] + '.o') for f in srcs]
-    if force or jobs or not os.path.exists(LIB):
+    manifest = os.path.join(OBJ, '.sources')                 # a removed or added source file changes the link line
+    listed = open(manifest).read().split() if os.path.exists(manifest) else None
+    if force or jobs or not os.path.exists(LIB) or listed != srcs or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr)
+        with open(manifest, 'w') as f:
+            f.write('\n'.join(srcs))
         if verbose:
             print(f'[build] linked {LIB}')
     return LIB
