@@ -168,3 +168,22 @@ def duplicate_data(dense_data, n_samples=1, mask_=True, get_discrete_data=False)
         disc = dense_data.get_new_object().mask(dense_data.node_mask, collapse=True)
         return dense_data, disc
     return dense_data
+
+
+def save_gen_rxn_smiles_to_file(filename, condition_idx, gen_rxns, true_rxn_str):
+    """utils/graph.py:786-800, byte for byte: `(cond i) true_rxn:` then one tab-indented line per generated reaction; condition 0
+    truncates the file, later conditions append.  `true_rxn_str`: the string mol.rxn_list_to_str(true_rcts, true_prods) gives (the
+    chemistry side is the caller's: rdkit is not part of this package)."""
+    with open(filename, 'w' if condition_idx == 0 else 'a') as f:
+        f.write(f'(cond {condition_idx}) {true_rxn_str}:\n')
+        f.writelines([f'\t{p}\n' for p in gen_rxns])
+
+
+def save_samples_to_file_without_weighted_prob(filename, condition_idx, gen_rxns, true_rxn_strs):
+    """utils/graph.py:772-784: per condition a header line and one line `(rxn string, [elbo, loss_t, loss_0, count])` per distinct
+    sample.  gen_rxns: {key: [dict(rxn=str, elbo=, loss_t=, loss_0=, count=)]} in condition order; true_rxn_strs: one string each."""
+    import os
+    with open(filename, 'a' if os.path.exists(filename) else 'w') as f:
+        for i, p in enumerate(gen_rxns):
+            f.write(f'(cond {condition_idx + i}) {true_rxn_strs[i]}:\n')
+            f.writelines([f'\t{(x["rxn"], [x["elbo"], x["loss_t"], x["loss_0"], x["count"]])}\n' for x in gen_rxns[p]])

@@ -137,6 +137,22 @@ class PlaceHolder:
         return PlaceHolder(X=pick(self.X, n), E=pick(self.E, n, n), y=pick(self.y, -1), node_mask=pick(self.node_mask, n),
                            atom_map_numbers=pick(self.atom_map_numbers, n), mol_assignments=pick(self.mol_assignments, n))
 
+    def to_sparse(self):
+        """The fields of the torch_geometric `Data` objects PlaceHolder.pyg() builds (utils/placeholder.py:165-179), one dict per
+        graph, with the reference's dtypes: x uint8 class indices, edge_index int16 (2,M) and edge_attr uint8 (M) of the non-zero
+        entries of the collapsed E in row-major order (torch_geometric.utils.dense_to_sparse), y / node_mask / mask_atom_mapping /
+        mol_assignment uint8.  torch_geometric is not a dependency here: wrapping each dict as Data(**d) and Batch.from_data_list
+        gives the reference's object (what its gzip-pickled `samples_*.gz` files hold)."""
+        X = self.X if self.X.dim() == 2 else self.X.argmax(-1)
+        E = self.E if self.E.dim() == 3 else self.E.argmax(-1)
+        out = []
+        for i in range(X.shape[0]):
+            idx = E[i].nonzero().t().contiguous()
+            out.append(dict(x=X[i].to(torch.uint8), edge_index=idx.to(torch.int16), edge_attr=E[i][idx[0], idx[1]].to(torch.uint8),
+                            y=self.y.to(torch.uint8) if self.y is not None else None, node_mask=self.node_mask[i].to(torch.uint8),
+                            mask_atom_mapping=self.atom_map_numbers[i].to(torch.uint8), mol_assignment=self.mol_assignments[i].to(torch.uint8)))
+        return out
+
     def serialize(self):
         return {f.name: (getattr(self, f.name).detach().cpu().numpy().tolist() if getattr(self, f.name) is not None else None) for f in fields(self)}
 

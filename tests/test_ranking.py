@@ -27,3 +27,34 @@ def test_sort_by_elbo_and_weighted_ranking_match_reference():
         assert [r['sample_idx'] for r in got[k]] == [r['sample_idx'] for r in want[k]]
         for a, b in zip(got[k], want[k]):
             assert abs(a['weighted_prob'] - b['weighted_prob']) <= 1e-12 and a['rcts'] == b['rcts'] and a['count'] == b['count']
+
+
+def test_sparse_fields_and_text_formats(tmp_path):
+    """SURVEY 8 f-4 (what can be built without torch_geometric / rdkit): the per-graph fields of PlaceHolder.pyg()
+    (utils/placeholder.py:165-179, dense_to_sparse order and dtypes) and the samples_*.txt layout (utils/graph.py:786-800)."""
+    import numpy as np
+    import torch
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import graph
+    g = torch.Generator().manual_seed(0)
+    B, n = 3, 7
+    E = torch.randint(0, 4, (B, n, n), generator=g); E = torch.triu(E, 1); E = E + E.transpose(1, 2)
+    X = torch.randint(0, 9, (B, n), generator=g)
+    ph = PlaceHolder(X=X, E=E, y=torch.zeros(B, 1), node_mask=torch.ones(B, n, dtype=torch.bool), atom_map_numbers=torch.arange(n).repeat(B, 1),
+                     mol_assignments=torch.ones(B, n, dtype=torch.long))
+    fields = ph.to_sparse()
+    one_hot = PlaceHolder(X=torch.nn.functional.one_hot(X, 9).float(), E=torch.nn.functional.one_hot(E, 4).float(), y=ph.y, node_mask=ph.node_mask,
+                          atom_map_numbers=ph.atom_map_numbers, mol_assignments=ph.mol_assignments).to_sparse()
+    for i, d in enumerate(fields):
+        rows, cols = np.nonzero(E[i].numpy())                       # row-major order, as dense_to_sparse
+        assert d['edge_index'].dtype == torch.int16 and d['edge_attr'].dtype == torch.uint8 and d['x'].dtype == torch.uint8
+        assert np.array_equal(d['edge_index'].numpy(), np.stack([rows, cols])) and np.array_equal(d['edge_attr'].numpy(), E[i].numpy()[rows, cols])
+        assert np.array_equal(d['x'].numpy(), X[i].numpy()) and d['mask_atom_mapping'].tolist() == list(range(n))
+        assert all(torch.equal(d[k], one_hot[i][k]) for k in ('x', 'edge_index', 'edge_attr'))
+    f = str(tmp_path / 'samples.txt')
+    graph.save_gen_rxn_smiles_to_file(f, 0, ['A.B>>C', 'D>>C'], 'A.B>>C')
+    graph.save_gen_rxn_smiles_to_file(f, 1, ['E>>F'], 'G>>F')
+    assert open(f).read() == '(cond 0) A.B>>C:\n\tA.B>>C\n\tD>>C\n(cond 1) G>>F:\n\tE>>F\n'
+    f2 = str(tmp_path / 'eval.txt')
+    graph.save_samples_to_file_without_weighted_prob(f2, 4, {'a': [dict(rxn='A>>B', elbo=1.5, loss_t=1.0, loss_0=0.5, count=3)]}, ['A>>B'])
+    assert open(f2).read() == "(cond 4) A>>B:\n\t('A>>B', [1.5, 1.0, 0.5, 3])\n"
