@@ -16,16 +16,16 @@ from .placeholder import PlaceHolder
 
 
 def reactions_sorted_with_weighted_prob(restructured_data, lambda_value):
-    """utils/graph.py:709-736: per product, weighted_prob = lambda * softmax(-elbo) + (1 - lambda) * count share; sort descending."""
-    restructured_data = copy.deepcopy(restructured_data)
-    for product, reactions_list in restructured_data.items():
-        sum_exp_elbo = sum(np.exp(-reaction['elbo']) for reaction in reactions_list)
-        sum_counts = sum(reaction['count'] for reaction in reactions_list)
-        for reaction in reactions_list:
-            exp_elbo = np.exp(-reaction['elbo'])
-            reaction['weighted_prob'] = (exp_elbo / sum_exp_elbo) * lambda_value + (reaction['count'] / sum_counts) * (1 - lambda_value)
-        restructured_data[product] = sorted(reactions_list, key=lambda x: x['weighted_prob'], reverse=True)
-    return restructured_data
+    """utils/graph.py:709-736 on arrays: per product, weighted_prob = lambda * softmax(-elbo) + (1 - lambda) * count share, reactions in
+    descending order of it (ties keep their input order, as the reference's stable sort does).  Returns new dicts; the input is left
+    untouched.  The two normalisers are accumulated left to right (cumsum), which is the reference's summation order bit for bit."""
+    ranked = {}
+    for product, reactions in restructured_data.items():
+        p_elbo = np.exp(-np.array([rx['elbo'] for rx in reactions], dtype=np.float64))
+        counts = np.array([rx['count'] for rx in reactions], dtype=np.float64)
+        w = p_elbo / np.cumsum(p_elbo)[-1] * lambda_value + counts / np.cumsum(counts)[-1] * (1 - lambda_value) if len(reactions) else p_elbo
+        ranked[product] = [dict(copy.deepcopy(reactions[i]), weighted_prob=w[i]) for i in np.argsort(-w, kind='stable')]
+    return ranked
 
 
 def _to_device(batch, dev):
@@ -109,23 +109,22 @@ class DiscreteDenoisingDiffusionRxn(DiscreteDenoisingDiffusion):
     def estimate_elbo_with_repeats(self, final_samples_one_hot, noise_fn=None):
         """diffusion_rxn.py:606-641: mean over cfg.test.repeat_elbo estimates of the per-sample bound, the batch cut into chunks
         of cfg.test.elbo_batch_size samples.  Everything stays on the device (the reference reduces on the CPU)."""
-        chunk_size = getattr(self.cfg.test, 'elbo_batch_size', None)
         total = final_samples_one_hot.X.shape[0]
-        if chunk_size is None or chunk_size <= 0 or chunk_size >= total:
-            chunk_ranges = [(0, total)]
-        else:
-            chunk_ranges = [(s, min(s + chunk_size, total)) for s in range(0, total, chunk_size)]
-        reps = [[], [], []]
-        for _ in range(self.cfg.test.repeat_elbo):
-            chunks = [[], [], []]
-            for start, end in chunk_ranges:
-                inp = final_samples_one_hot if len(chunk_ranges) == 1 else final_samples_one_hot.subset_by_idx(start, end)
-                out = self.elbo(dense_true=inp, avg_over_batch=False, noise_fn=noise_fn)
-                for dst, v in zip(chunks, out):
-                    dst.append(v.float())
-            for dst, c in zip(reps, chunks):
-                dst.append(torch.cat(c, dim=0).unsqueeze(0))
-        return tuple(torch.cat(r, dim=0).mean(0) for r in reps)          # elbos, loss_t, loss_0: (bs * n_samples,)
+        step = getattr(self.cfg.test, 'elbo_batch_size', None)
+        step = total if not step or step <= 0 else min(int(step), total)
+        repeats = int(self.cfg.test.repeat_elbo)
+        # running sums of the three per-sample terms (elbo, loss_t, loss_0) on the device; a chunk writes its own slice, so neither the
+        # per-repeat lists nor the concatenations of the reference exist here.  mean over repeats = sum / repeats (fp32, repeat order)
+        acc = torch.zeros(3, total, dtype=torch.float32, device=final_samples_one_hot.X.device)
+        for _ in range(repeats):
+            for lo in range(0, max(total, 1), max(step, 1)):
+                hi = min(lo + step, total)
+                part = final_samples_one_hot if (lo, hi) == (0, total) else final_samples_one_hot.subset_by_idx(lo, hi)
+                terms = self.elbo(dense_true=part, avg_over_batch=False, noise_fn=noise_fn)
+                for k, v in enumerate(terms):
+                    acc[k, lo:hi] += v.float()
+        acc /= repeats
+        return acc[0], acc[1], acc[2]                                   # elbos, loss_t, loss_0: (bs * n_samples,)
 
     @torch.no_grad()
     def sort_by_elbo(self, elbos, loss_t, loss_0, rct_smiles, prod_smiles, is_unique, counts, bs, n_samples, k=[10]):
