@@ -109,8 +109,13 @@ def train_main(args, dev, dist, world, rank):
     model = DiscreteDenoisingDiffusion(cfg, make_info(), device=dev).train()
     true = S.make_reaction_batch(B, n, seed=1 + rank, P=None)
     data = PlaceHolder(**{k: v.to(dev) for k, v in true.items()})
-    opt = FlatAdamW(model.model.parameters(), lr=2e-4, weight_decay=1e-12, amsgrad=True)
+    opt = FlatAdamW(model.model.parameters(), lr=2e-4, weight_decay=1e-12, amsgrad=True, device_step=args.graph)
     group = None
+    step_fn = lambda: model.train_one_step(data, opt, group=group)
+    if args.graph:                                            # the whole step replayed as one HIP graph (diffalign_amd/graphs.py)
+        from diffalign_amd.graphs import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, data, group=group)
+        step_fn = lambda: gstep(data)
 
     def sync():
         if dist is not None:
@@ -119,12 +124,12 @@ def train_main(args, dev, dist, world, rank):
 
     losses = []
     for _ in range(args.warmup):
-        model.train_one_step(data, opt, group=group)
+        step_fn()
     sync()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(model.train_one_step(data, opt, group=group))
+        losses.append(step_fn().clone())
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -138,7 +143,7 @@ def train_main(args, dev, dist, world, rank):
                           'config': {'workload': f'NOT the headline -- BASELINE.json configs[3]: align_absorbing training step, loss {args.train_loss}, '
                                                  f'batch {B}/GPU padded to n={n} (USPTO-like sizes), dropout 0.2, AdamW(amsgrad), extra features and '
                                                  'Laplacian position encodings computed on the device inside the step' , 'global_batch': B * world,
-                                     'parallelism': f'dp{world} (one flat-gradient all-reduce per step)'},
+                                     'parallelism': f'dp{world} (one flat-gradient all-reduce per step)', 'hip_graph': bool(args.graph)},
                           'loss_first_last': [float(losses[0]), float(losses[-1])],
                           'peak_hbm_GB': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if dist is not None:

@@ -456,6 +456,27 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const floa
   p[t] = x - (lr / bc1) * mm / den;
 }
 
+// The same update with the step number in device memory (*step holds the number of updates done so far): the bias corrections are
+// computed on the device, so the launch carries no per-step host value and can be replayed from a HIP graph.  k_adamw_tick follows it.
+__global__ void __launch_bounds__(256) k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, long long N, float lr, float b1, float b2, float eps, float wd,
+                                                   const int* __restrict__ step, float grad_scale) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const float st = (float)(*step + 1);
+  const float bc1 = 1.f - powf(b1, st), bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  const float gr = g[t] * grad_scale;
+  float x = p[t];
+  x *= 1.f - lr * wd;
+  const float mm = b1 * m[t] + (1.f - b1) * gr, vv = b2 * v[t] + (1.f - b2) * gr * gr;
+  m[t] = mm; v[t] = vv;
+  float den;
+  if (vmax) { const float vm = fmaxf(vmax[t], vv); vmax[t] = vm; den = sqrtf(vm) / bc2_sqrt + eps; }
+  else den = sqrtf(vv) / bc2_sqrt + eps;
+  p[t] = x - (lr / bc1) * mm / den;
+}
+__global__ void k_adamw_tick(int* step) { *step += 1; }
+
 static inline unsigned grid_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 template <int K, bool IS_E>
@@ -606,6 +627,18 @@ int da_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
   k_adamw<<<grid_for(N, 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, N, lr, beta1, beta2, eps, weight_decay,
                                                           bc1, bc2, grad_scale);
   DA_CHECK_LAUNCH("da_adamw");
+  return DA_OK;
+}
+
+// da_adamw with the step counter in device memory (int, starts at 0, incremented here): for optimiser steps replayed from a HIP graph.
+int da_adamw_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int* step_counter, float grad_scale, void* stream) {
+  DA_CHECK_ARG(N >= 0 && step_counter && param && grad && exp_avg && exp_avg_sq, "da_adamw_devstep: arguments");
+  if (N > 0)
+    k_adamw_dev<<<grid_for(N, 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, N, lr, beta1, beta2, eps,
+                                                                  weight_decay, step_counter, grad_scale);
+  k_adamw_tick<<<1, 1, 0, (hipStream_t)stream>>>(step_counter);
+  DA_CHECK_LAUNCH("da_adamw_devstep");
   return DA_OK;
 }
 

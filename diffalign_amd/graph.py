@@ -30,6 +30,18 @@ def get_index_from_states(atom_decoder, bond_decoder, node_states_to_mask, edge_
     return node_idx, edge_idx
 
 
+_STATES = {}
+
+
+def _states_on(dev, idx: tuple) -> torch.Tensor:
+    """The list of always-masked node classes on the device, uploaded once per (device, list): no host-to-device copy per call
+    (one would also be illegal while a HIP graph is being captured)."""
+    key = (str(dev), idx)
+    if key not in _STATES:
+        _STATES[key] = torch.tensor(idx, dtype=torch.int32, device=dev)
+    return _STATES[key]
+
+
 def get_node_masks(orig: PlaceHolder, atom_decoder, bond_decoder, mask_nodes, mask_edges, node_states_to_mask=(),
                    edge_states_to_mask=(), include_supernode=True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Per-node free masks (bool (B,n) each): closed form of graph.py:462-534."""
@@ -41,7 +53,7 @@ def get_node_masks(orig: PlaceHolder, atom_decoder, bond_decoder, mask_nodes, ma
     B, n, kx = orig.X.shape
     dev = orig.X.device
     X = orig.X.contiguous().float()
-    states = torch.tensor(node_idx, dtype=torch.int32, device=dev)
+    states = _states_on(dev, tuple(node_idx))
     mx = torch.empty(B, n, dtype=torch.uint8, device=dev)
     me = torch.empty(B, n, dtype=torch.uint8, device=dev)
     am = orig.atom_map_numbers.contiguous() if orig.atom_map_numbers is not None else None

@@ -60,3 +60,45 @@ class GraphedReverseStep:
         self._set_t(t)
         self.graph.replay()
         return self.z
+
+
+class GraphedTrainStep:
+    """One whole training step -- apply_noise, apply_mask, extra features, the differentiable fp32 forward, the objective, backward(),
+    the gradient gather, (the data-parallel all-reduce) and the fused AdamW -- captured once as a HIP graph and replayed per batch.
+    An eager step issues ~2,400 launches from Python and autograd and is host-bound at the reference's batch size (DESIGN.md 6);
+    the replay costs one launch.  What changes between steps lives in static device buffers: the batch (copied in before a replay),
+    the positional encodings (they depend on the condition only: computed outside, eagerly) and the optimiser's step counter
+    (optim.FlatAdamW(device_step=True)).  Random draws (t, the noise, dropout masks) come from torch's graph-safe device generator.
+    One graph per batch shape."""
+
+    def __init__(self, model, optimizer, example: PlaceHolder, warmup: int = 3, group=None):
+        assert optimizer.step_dev is not None, 'GraphedTrainStep needs optim.FlatAdamW(..., device_step=True)'
+        assert model.model.training, 'call model.train() first'
+        self.model, self.opt, self.group = model, optimizer, group
+        self.data = example.get_new_object()                 # static copies (get_new_object clones every field)
+        self.pos = model.get_pos_encodings(self.data)
+        if self.pos is not None:
+            self.pos = self.pos.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):                          # settles allocator pools, workspaces and lazily built tables
+                model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos)
+
+    def __call__(self, data: PlaceHolder) -> torch.Tensor:
+        """One optimisation step on `data` (same shapes as the example).  Returns the (static) loss tensor of this step."""
+        from . import _lib as L
+        for name in ('X', 'E', 'y', 'node_mask', 'atom_map_numbers', 'mol_assignments'):
+            dst, src = getattr(self.data, name), getattr(data, name)
+            if dst is not None and src is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        if self.pos is not None and data is not self.data:
+            self.pos.copy_(self.model.get_pos_encodings(self.data))
+        self.graph.replay()
+        self.opt.steps += 1
+        L.weights_epoch += 1                                 # the bf16 inference path re-packs on its next call
+        return self.loss

@@ -10,7 +10,7 @@ from . import _lib as L
 
 
 class FlatAdamW:
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, device_step=False):
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), 'fp32 parameters on a HIP device'
         dev = self.params[0].device
@@ -29,6 +29,8 @@ class FlatAdamW:
         self.max_exp_avg_sq = torch.zeros(n, device=dev) if amsgrad else None
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.steps = 0
+        # device_step: the update count lives on the device (da_adamw_devstep), so that step() can be captured in a HIP graph
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if device_step else None
         self._written = set()      # indices of parameters whose gradient slot has ever been filled
 
     def zero_grad(self):
@@ -59,6 +61,12 @@ class FlatAdamW:
     def step(self, grad_scale: float = 1.0):
         """One fused AdamW pass over the flat buffers; call after `gather` (and after the gradient all-reduce)."""
         self.steps += 1
+        if self.step_dev is not None:
+            L.check(L.lib().da_adamw_devstep(L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                             L.ptr(self.max_exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                             self.weight_decay, L.ptr(self.step_dev), float(grad_scale), L.stream()), 'da_adamw_devstep')
+            L.weights_epoch += 1
+            return
         L.check(L.lib().da_adamw(L.ptr(self.flat_param), L.ptr(self.flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                  L.ptr(self.max_exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                  self.weight_decay, self.steps, float(grad_scale), L.stream()), 'da_adamw')

@@ -77,6 +77,6 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
         pair = (sel[:, :, None] & sel[:, None, :])[..., None]
         bi = torch.arange(B, device=X.device)[:, None, None]
         Eg = E[bi, idx[:, :, None], idx[:, None, :]][..., :ke]
-        first = torch.zeros(ke, device=X.device); first[0] = 1.0
+        first = (torch.arange(ke, device=X.device) == 0).float()          # class 0; built on the device (graph-capturable)
         Eo = Eo + m.skip_scaling * Eg * pair + m.skip_scaling_2 * first * (~pair)
     return Xo, Eo, yo

@@ -40,7 +40,7 @@ class TrainingMixin:
     """Needs from the host object: cfg, T, transition_model, dataset_info, model, forward, apply_noise, elbo_batch_quick."""
 
     def training_step(self, data: PlaceHolder, i: int = 0, device=None, t_int: Optional[torch.Tensor] = None, noise=None,
-                      z_t: Optional[PlaceHolder] = None):
+                      z_t: Optional[PlaceHolder] = None, pos_encodings=None, want_terms: bool = True):
         """diffusion_abstract.py:134-225.  `data`: dense PlaceHolder on the device (the reference's graph.to_dense is the data
         loader's side).  Returns (loss_X, loss_E, loss) as the reference does -- values, without an autograd graph; the
         context the backward needs stays in self._train_ctx.  t_int / noise / z_t fix the reference's random draws."""
@@ -66,11 +66,11 @@ class TrainingMixin:
             # the differentiable path: fp32 training forward under autograd (train_forward.py), the objective as one
             # autograd.Function whose backward is da_ce_grad / da_vb_grad; `loss.backward()` then fills every parameter's .grad
             from .autograd_ops import DiffusionLoss
-            pred = self.forward(z_t=z_t)
+            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)   # pos_encodings: precomputed (they depend on the condition only)
             loss = DiffusionLoss.apply(pred.X, pred.E, self, dense_data, z_keep, node_masks, loss_kind)
             self._train_ctx = None
             loss_X = loss_E = torch.zeros((1,))
-            if loss_kind == 'ce':
+            if loss_kind == 'ce' and want_terms:      # the per-element CE terms the reference also returns (a boolean gather: a host sync)
                 with torch.no_grad():
                     rX, rE = E_.elbo_rows(E_.LOGP, dense_data, logits=pred.get_new_object(X=pred.X.detach(), E=pred.E.detach()))
                     mx, me = node_masks[0].bool(), node_masks[1].bool()
@@ -102,13 +102,13 @@ class TrainingMixin:
         self._train_ctx = dict(pred=pred, data=dense_data, node_masks=node_masks, saved=saved, loss_kind=loss_kind, lam=lam)
         return loss_X, loss_E, loss
 
-    def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None):
+    def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None, pos_encodings=None):
         """training/helpers.py:130-142 for one batch: zero_grad, training_step, backward, gradient all-reduce over `group` (data
         parallel: one process per GPU, RCCL), fused AdamW step.  Returns the (detached) loss."""
         from . import distributed
         assert self.model.training, 'call model.train() first'
         optimizer.zero_grad()
-        _, _, loss = self.training_step(data, i, t_int=t_int, noise=noise, z_t=z_t)
+        _, _, loss = self.training_step(data, i, t_int=t_int, noise=noise, z_t=z_t, pos_encodings=pos_encodings, want_terms=False)
         loss.backward()
         optimizer.gather()
         world = distributed.allreduce_flat_gradient(optimizer.flat_grad, group=group)
