@@ -38,7 +38,7 @@ SIGNATURES = {
     'da_ce_grad': 'i:pppppppffppiiiip',
     'da_skip_grad': 'i:pppipippiiiip',
     'da_attn_core_fwd': 'i:ppppppppfppppiiip',
-    'da_attn_core_bwd': 'i:pppppppfppppppppppppiiip',
+    'da_attn_core_bwd': 'i:pppppppfpppppppppppppqiiip', 'da_attn_core_bwd_workspace': 'q:iii',
     'da_layernorm_bwd': 'i:pppppppqqip',
     'da_pool_stats_fwd': 'i:ppppqiiip', 'da_linear_wgrad_workspace': 'q:qii', 'da_linear_wgrad': 'i:pppppqqiip',
     'da_pool_stats_bwd': 'i:pppppiiip',

@@ -93,9 +93,10 @@ class AttnCore(Function):
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
         dE1, dE2 = torch.empty_like(E1), torch.empty_like(E1)
         dye1, dye2 = torch.empty_like(ye2), torch.empty_like(ye2)
+        ws = _workspace(Q.device, L.lib().da_attn_core_bwd_workspace(B, n, dx))
         L.check(L.lib().da_attn_core_bwd(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm_u8), L.ptr(ye2), ctx.qscale, L.ptr(wV),
                                          L.ptr(sm), L.ptr(sl), L.ptr(dZ), L.ptr(dwV), L.ptr(dQ), L.ptr(dK), L.ptr(dV), L.ptr(dE1), L.ptr(dE2),
-                                         L.ptr(dye1), L.ptr(dye2), B, n, dx, L.stream()), 'da_attn_core_bwd')
+                                         L.ptr(dye1), L.ptr(dye2), L.ptr(ws), ws.numel(), B, n, dx, L.stream()), 'da_attn_core_bwd')
         return dQ, dK, dV, dE1, dE2, None, dye1, dye2, None
 
 

@@ -127,6 +127,143 @@ __global__ void __launch_bounds__(256 * ATT_JS) k_attn_bwd(const float* __restri
   }
 }
 
+// The same two kernels with FOUR channels per thread (16-byte loads and stores: a wave instruction moves 1 KiB instead of 256 B of
+// the 321 MB streams, which is what bounds them) for dx % 4 == 0 with dx / 4 dividing 256.  A workgroup of 256 threads = dx / 4 channel
+// quads x JS key slices (slice s walks the keys j = s, s + JS, ...); the slices' softmax states (forward) and dQ / dye sums
+// (backward) meet in LDS.  Same arithmetic per element; sums over keys are grouped by slice.
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__global__ void __launch_bounds__(256) k_attn_fwd4(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                   const float* __restrict__ ye1, const float* __restrict__ ye2, float qscale,
+                                                   float* __restrict__ Z, float* __restrict__ wV, float* __restrict__ smax,
+                                                   float* __restrict__ ssum, int n, int dx) {
+  extern __shared__ float s_st[];                                         // [3][JS][dx]: running max, sum, weighted sum per slice
+  const int CW4 = dx >> 2, JS = 256 / CW4;
+  const int c = (threadIdx.x % CW4) * 4, js = threadIdx.x / CW4;
+  const int b = blockIdx.y, i = blockIdx.x;
+  const size_t row = (size_t)b * n + i;
+  const bool mi = nm[row] != 0;
+  const f32x4 q = ld4(Q + row * dx + c) * qscale, f1 = ld4(ye1 + (size_t)b * dx + c), f2 = ld4(ye2 + (size_t)b * dx + c) + 1.f;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l = {0.f, 0.f, 0.f, 0.f}, a = l;
+  for (int j = js; j < n; j += JS) {
+    const size_t kj = ((size_t)b * n + j) * dx + c, off = (row * n + j) * dx + c;
+    const bool pm = mi && nm[(size_t)b * n + j] != 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 e1 = pm ? ld4(E1 + off) : zero, e2 = pm ? ld4(E2 + off) : zero, v = ld4(V + kj);
+    const f32x4 y = (q * ld4(K + kj)) * (e1 + 1.f) + e2;
+    st4(Z + off, f1 + f2 * y);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float mn = fmaxf(m[t], y[t]), sc = expf(m[t] - mn), p = expf(y[t] - mn);
+      l[t] = l[t] * sc + p; a[t] = a[t] * sc + p * v[t]; m[t] = mn;
+    }
+  }
+  float* sm = s_st + (size_t)js * dx + c;
+  st4(sm, m); st4(sm + (size_t)JS * dx, l); st4(sm + (size_t)2 * JS * dx, a);
+  __syncthreads();
+  if (js == 0) {
+    f32x4 M = m;
+    for (int s2 = 1; s2 < JS; ++s2) {
+      const f32x4 o = ld4(s_st + (size_t)s2 * dx + c);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) M[t] = fmaxf(M[t], o[t]);
+    }
+    f32x4 L = {0.f, 0.f, 0.f, 0.f}, A = L;
+    for (int s2 = 0; s2 < JS; ++s2) {
+      const float* o = s_st + (size_t)s2 * dx + c;
+      const f32x4 ms = ld4(o), ls = ld4(o + (size_t)JS * dx), as = ld4(o + (size_t)2 * JS * dx);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const float w = expf(ms[t] - M[t]); L[t] += ls[t] * w; A[t] += as[t] * w; }
+    }
+    st4(wV + row * dx + c, A / L); st4(smax + row * dx + c, M); st4(ssum + row * dx + c, L);
+  }
+}
+// dK, dV = sum over the row blocks' partial results (block order: deterministic)
+__global__ void __launch_bounds__(256) k_attn_fold(const float* __restrict__ pK, const float* __restrict__ pV, float* __restrict__ dK,
+                                                   float* __restrict__ dV, int nblk, long long quads) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= quads) return;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  for (int g = 0; g < nblk; ++g) { a += ld4(pK + ((size_t)g * quads + t) * 4); b += ld4(pV + ((size_t)g * quads + t) * 4); }
+  st4(dK + t * 4, a); st4(dV + t * 4, b);
+}
+template <int IB>
+__global__ void __launch_bounds__(256) k_attn_bwd4(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                   const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
+                                                   const float* __restrict__ smax, const float* __restrict__ ssum,
+                                                   const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
+                                                   float* __restrict__ dKp, float* __restrict__ dVp, float* __restrict__ dE1,
+                                                   float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
+  // dKp, dVp (gridDim.x, B, n, dx): this row block's contribution to dK, dV, every element written once (k_attn_fold sums the blocks
+  // in order).  With fp32 atomics on dK / dV instead, the kernel's time was proportional to the number of atomics (2.25 / 1.19 / 0.74 ms
+  // for 1 / 2 / 4 rows per block against ~0.2 ms of streaming).
+  extern __shared__ float s_red[];                                        // [JS][IB + 2][dx]
+  const int CW4 = dx >> 2, JS = 256 / CW4;
+  const int c = (threadIdx.x % CW4) * 4, js = threadIdx.x / CW4;
+  const int b = blockIdx.y, i0 = blockIdx.x * IB;
+  const int ni = min(IB, n - i0);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 f2 = ld4(ye2 + (size_t)b * dx + c) + 1.f;
+  f32x4 q[IB], m[IB], inv_l[IB], g[IB], D[IB], dq[IB], d1 = zero, d2 = zero;
+  bool mi[IB];
+#pragma unroll
+  for (int t = 0; t < IB; ++t) {
+    const size_t row = ((size_t)b * n + min(i0 + t, n - 1)) * dx + c;
+    q[t] = ld4(Q + row); m[t] = ld4(smax + row); inv_l[t] = 1.f / ld4(ssum + row); g[t] = ld4(dwV + row); D[t] = g[t] * ld4(wV + row);
+    dq[t] = zero; mi[t] = t < ni && nm[(size_t)b * n + i0 + t] != 0;
+  }
+  for (int j = js; j < n; j += JS) {
+    const size_t kj = ((size_t)b * n + j) * dx + c;
+    const bool mj = nm[(size_t)b * n + j] != 0;
+    const f32x4 k = ld4(K + kj), v = ld4(V + kj);
+    f32x4 dk = zero, dv = zero;
+#pragma unroll
+    for (int t = 0; t < IB; ++t) {
+      if (t < ni) {
+        const size_t off = (((size_t)b * n + i0 + t) * n + j) * dx + c;
+        const bool pm = mi[t] && mj;
+        const f32x4 e1 = (pm ? ld4(E1 + off) : zero) + 1.f, e2 = pm ? ld4(E2 + off) : zero, dz = ld4(dZ + off);
+        const f32x4 qk = (q[t] * k) * qscale;
+        const f32x4 y = qk * e1 + e2;
+        f32x4 attn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) attn[u] = expf(y[u] - m[t][u]);
+        attn *= inv_l[t];
+        const f32x4 dy = dz * f2 + attn * (g[t] * v - D[t]);
+        d1 += dz; d2 += dz * y;
+        st4(dE2 + off, pm ? dy : zero);
+        st4(dE1 + off, pm ? dy * qk : zero);
+        const f32x4 dqk = dy * e1 * qscale;
+        dq[t] += dqk * k;
+        dk += dqk * q[t];
+        dv += attn * g[t];
+      }
+    }
+    const size_t pj = (((size_t)blockIdx.x * gridDim.y + b) * n + j) * dx + c;
+    st4(dKp + pj, dk); st4(dVp + pj, dv);
+  }
+  float* mine = s_red + (size_t)js * (IB + 2) * dx + c;
+#pragma unroll
+  for (int t = 0; t < IB; ++t) st4(mine + (size_t)t * dx, dq[t]);
+  st4(mine + (size_t)IB * dx, d1); st4(mine + (size_t)(IB + 1) * dx, d2);
+  __syncthreads();
+  if (js == 0) {
+    for (int s2 = 1; s2 < JS; ++s2) {
+      const float* o = s_red + (size_t)s2 * (IB + 2) * dx + c;
+#pragma unroll
+      for (int t = 0; t < IB; ++t) dq[t] += ld4(o + (size_t)t * dx);
+      d1 += ld4(o + (size_t)IB * dx); d2 += ld4(o + (size_t)(IB + 1) * dx);
+    }
+#pragma unroll
+    for (int t = 0; t < IB; ++t)
+      if (t < ni) st4(dQ + ((size_t)b * n + i0 + t) * dx + c, dq[t]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { atomicAdd(dye1 + (size_t)b * dx + c + u, d1[u]); atomicAdd(dye2 + (size_t)b * dx + c + u, d2[u]); }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward, eps 1e-5.  s = the normalised input (a + b of the residual).  A row of D floats is held by D/4 lanes as one
 // float4 each (16-byte loads), so a wave covers 256/D rows per pass; grid-stride over rows.  dgamma / dbeta: per-workgroup partial
@@ -499,28 +636,62 @@ int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float
                      void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 0 && dx >= 1, "da_attn_core_fwd: sizes");
   if (B == 0 || n == 0) return DA_OK;
+  const bool quad = dx % 4 == 0 && dx / 4 <= 256 && 256 % (dx / 4) == 0 && getenv("DA_ATTN_SCALAR") == nullptr &&
+                    ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)E1 | (uintptr_t)E2 | (uintptr_t)ye1 | (uintptr_t)ye2 | (uintptr_t)Z |
+                       (uintptr_t)wV | (uintptr_t)smax | (uintptr_t)ssum) & 15) == 0);
+  if (quad) {
+    const int JS = 256 / (dx / 4);
+    k_attn_fwd4<<<dim3(n, B), 256, sizeof(float) * 3 * JS * dx, (hipStream_t)stream>>>(Q, K, V, E1, E2, node_mask, ye1, ye2, qscale, Z, wV, smax, ssum, n, dx);
+    DA_CHECK_LAUNCH("da_attn_core_fwd");
+    return DA_OK;
+  }
   k_attn_fwd<<<dim3(n, B), dx < 256 ? ((dx + 63) / 64) * 64 : 256, 0, (hipStream_t)stream>>>(Q, K, V, E1, E2, node_mask, ye1, ye2, qscale, Z, wV,
                                                                                          smax, ssum, n, dx);
   DA_CHECK_LAUNCH("da_attn_core_fwd");
   return DA_OK;
 }
 
+// Workspace of da_attn_core_bwd's fast path: per-row-block partial dK, dV.
+long long da_attn_core_bwd_workspace(int B, int n, int dx) {
+  if (B < 0 || n < 0 || dx < 1) return -1;
+  return (long long)sizeof(float) * 2 * ((n + 3) / 4) * B * n * dx;
+}
 int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
                      const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const float* dZ, const float* dwV,
-                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, int B, int n, int dx, void* stream) {
+                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, void* workspace, long long workspace_bytes,
+                     int B, int n, int dx, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 0 && dx >= 1, "da_attn_core_bwd: sizes");
   if (B == 0 || n == 0) return DA_OK;
   hipStream_t s = (hipStream_t)stream;
   const size_t nb = sizeof(float) * (size_t)B * n * dx, yb = sizeof(float) * (size_t)B * dx;
-  if (hipMemsetAsync(dK, 0, nb, s) != hipSuccess || hipMemsetAsync(dV, 0, nb, s) != hipSuccess || hipMemsetAsync(dye1, 0, yb, s) != hipSuccess ||
-      hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) { da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP; }
+  if (hipMemsetAsync(dye1, 0, yb, s) != hipSuccess || hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) {
+    da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP;
+  }
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("DA_ATTN_BWD"); variant = e ? atoi(e) : 2; }
+  constexpr int QIB = 4;                                                    // query rows per workgroup of the quad kernel
+  const long long need = (long long)sizeof(float) * 2 * ((n + QIB - 1) / QIB) * B * n * dx;
+  const bool quad = variant < 10 && dx % 4 == 0 && dx / 4 <= 256 && 256 % (dx / 4) == 0 && workspace && workspace_bytes >= need &&
+                    (((uintptr_t)workspace | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0 &&
+                    ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)E1 | (uintptr_t)E2 | (uintptr_t)ye2 | (uintptr_t)wV | (uintptr_t)smax |
+                       (uintptr_t)ssum | (uintptr_t)dZ | (uintptr_t)dwV | (uintptr_t)dQ | (uintptr_t)dE1 | (uintptr_t)dE2) & 15) == 0);
+  if (quad) {                                                               // dK, dV: per-block partials + ordered fold, no atomics
+    const int JS = 256 / (dx / 4), nblk = (n + QIB - 1) / QIB;
+    float* pK = (float*)workspace; float* pV = pK + (size_t)nblk * B * n * dx;
+    k_attn_bwd4<QIB><<<dim3(nblk, B), 256, sizeof(float) * JS * (QIB + 2) * dx, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ,
+                                                                                 pK, pV, dE1, dE2, dye1, dye2, n, dx);
+    const long long quads = (long long)B * n * dx / 4;
+    k_attn_fold<<<grid_for(quads, 256), 256, 0, s>>>(pK, pV, dK, dV, nblk, quads);
+    DA_CHECK_LAUNCH("da_attn_core_bwd");
+    return DA_OK;
+  }
+  if (hipMemsetAsync(dK, 0, nb, s) != hipSuccess || hipMemsetAsync(dV, 0, nb, s) != hipSuccess) { da_set_error("da_attn_core_bwd: memset failed"); return DA_ERR_HIP; }
   const int cw = dx < 256 ? ((dx + 63) / 64) * 64 : 256;
-  static int variant = -1;                                                // DA_ATTN_BWD=<rows per block><key slices>, e.g. 42 (tuning only)
-  if (variant < 0) { const char* e = getenv("DA_ATTN_BWD"); variant = e ? atoi(e) : 42; }
+  const int scalar_variant = variant < 10 ? 42 : variant;                                                // DA_ATTN_BWD=<rows per block><key slices>, e.g. 42 (tuning only)
 #define ATT_LAUNCH(IB_, JS_)                                                                                                      \
   k_attn_bwd<IB_, JS_><<<dim3((n + IB_ - 1) / IB_, B), cw * JS_, sizeof(float) * JS_ * (IB_ + 2) * cw, s>>>(                       \
       Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ, dK, dV, dE1, dE2, dye1, dye2, n, dx)
-  switch (variant) {
+  switch (scalar_variant) {
     case 11: ATT_LAUNCH(1, 1); break;  case 12: ATT_LAUNCH(1, 2); break;  case 21: ATT_LAUNCH(2, 1); break;  case 22: ATT_LAUNCH(2, 2); break;
     case 24: ATT_LAUNCH(2, 4); break;  case 41: ATT_LAUNCH(4, 1); break;  case 44: ATT_LAUNCH(4, 4); break;  case 82: ATT_LAUNCH(8, 2); break;
     case 84: ATT_LAUNCH(8, 4); break;  default: ATT_LAUNCH(4, 2); break;

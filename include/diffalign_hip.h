@@ -143,10 +143,14 @@ int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float
                      const float* ye1, const float* ye2, float qscale, float* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
                      void* stream);
 /* Its backward: from dZ (B,n,n,dx) and dwV (B,n,dx) to dQ, dK, dV (B,n,dx), dE1, dE2 (B,n,n,dx; zero on masked pairs), dye1, dye2
- * (B,dx).  dK, dV, dye1, dye2 are cleared here and summed with fp32 atomics, one per block of 8 query rows (order-dependent in the last bits). */
+ * (B,dx).  With a 16-byte aligned workspace of da_attn_core_bwd_workspace bytes and dx % 4 == 0: four channels per thread, dK / dV as
+ * per-row-block partial results folded in block order (deterministic); without it: fp32 atomics on dK / dV (order-dependent in the last
+ * bits).  dye1, dye2: one atomic per row block and channel in both forms. */
 int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2, const uint8_t* node_mask,
                      const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const float* dZ, const float* dwV,
-                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, int B, int n, int dx, void* stream);
+                     float* dQ, float* dK, float* dV, float* dE1, float* dE2, float* dye1, float* dye2, void* workspace, long long workspace_bytes,
+                     int B, int n, int dx, void* stream);
+long long da_attn_core_bwd_workspace(int B, int n, int dx);
 /* Weight and bias gradient of an nn.Linear applied to R rows (training/helpers.py:139 `loss.backward()` for the per-pair Linears e_mul,
  * e_add, e_out, linE1, linE2, mlp_in_E.2, mlp_out_E.0, where R = B n n): dW (out,in) = dY^T X, db (out) = column sums of dY (NULL: skipped);
  * X (R,in), dY (R,out) fp32 row-major.  Split over R, fp32 MFMA, partial results in `workspace` (da_linear_wgrad_workspace bytes), summed in

@@ -31,10 +31,11 @@ fwd = lambda: L.check(L.lib().da_attn_core_fwd(L.ptr(Q), L.ptr(K), L.ptr(V), L.p
                                                L.ptr(wV), L.ptr(sm), L.ptr(sl), B, n, dx, L.stream()), 'fwd')
 timed('attn_core_fwd', fwd, 3 * big)
 dZ, dwV = r(B, n, n, dx), r(B, n, dx)
+wsA = torch.empty(int(L.lib().da_attn_core_bwd_workspace(B, n, dx)), dtype=torch.uint8, device=dev)
 dQ, dK, dV, dE1, dE2, d1, d2 = (torch.empty_like(t) for t in (Q, Q, Q, E1, E1, ye1, ye1))
 bwd = lambda: L.check(L.lib().da_attn_core_bwd(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm), L.ptr(ye2), 0.177, L.ptr(wV), L.ptr(sm),
                                                L.ptr(sl), L.ptr(dZ), L.ptr(dwV), L.ptr(dQ), L.ptr(dK), L.ptr(dV), L.ptr(dE1), L.ptr(dE2), L.ptr(d1),
-                                               L.ptr(d2), B, n, dx, L.stream()), 'bwd')
+                                               L.ptr(d2), L.ptr(wsA), wsA.numel(), B, n, dx, L.stream()), 'bwd')
 timed(f'attn_core_bwd [{os.environ.get("DA_ATTN_BWD", "42")}]', bwd, 5 * big)
 del Z, dZ, dE1, dE2, E2
 ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
