@@ -352,3 +352,37 @@ def test_device_step_adamw_and_graphed_training_step():
         model.eval(); l1 = probe()
     assert l1 < 0.8 * l0, (l0, l1)
     print('graphed training: probe loss', l0, '->', l1)
+
+
+def test_plain_graph_transformer_gradients_vs_oracle():
+    """GraphTransformerWithY (no atom maps, no positional encodings, no skip connection: transformer_model_with_y.py:33-112) in
+    train mode: logits and every parameter gradient against autograd through the oracle."""
+    import torch.nn as nn
+    from tests.golden.common import tiny_dims
+    from diffalign_amd.transformer_model_with_y import GraphTransformerWithY
+    dims = tiny_dims()
+    torch.manual_seed(12)
+    B, n = 3, 19
+    m = GraphTransformerWithY(2, {'X': KX, 'E': KE, 'y': 1}, dims['hidden_mlp_dims'], dims['hidden_dims'], {'X': KX, 'E': KE, 'y': 1},
+                              nn.ReLU(), nn.ReLU(), dropout=0.0)
+    g = torch.Generator().manual_seed(13)
+    nm = ragged_mask(B, n, g)
+    X = F.one_hot(torch.randint(0, KX, (B, n), generator=g), KX).float()
+    Ec = torch.triu(torch.randint(0, KE, (B, n, n), generator=g), 1); Ec = Ec + Ec.transpose(1, 2)
+    E = F.one_hot(Ec, KE).float()
+    y = torch.rand(B, 1, generator=g)
+    gX, gE = torch.randn(B, n, KX, generator=g), torch.randn(B, n, n, KE, generator=g)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    lX, lE, _ = O.denoiser_forward(sd, X, E, y, nm, 2, dims['hidden_dims']['n_head'], (KX, KE, 1))
+    ((lX * gX).sum() + (lE * gE).sum()).backward()
+    m = m.to(D).train()
+    Xo, Eo, yo, _ = m(X.to(D), E.to(D), y.to(D), nm.to(D))
+    assert (Xo.detach().cpu() - lX.detach()).abs().max() <= 1e-4 and (Eo.detach().cpu() - lE.detach()).abs().max() <= 1e-4
+    ((Xo * gX.to(D)).sum() + (Eo * gE.to(D)).sum()).backward()
+    for name, p in m.named_parameters():
+        want = sd[name].grad
+        if want is None:
+            assert p.grad is None, name
+            continue
+        err = float((p.grad.cpu() - want).norm()) / (float(want.norm()) + 1e-6)
+        assert err <= 1e-4, (name, err)
