@@ -770,8 +770,9 @@ def pos_enc_laplacian(E_classes: Tensor, atom_map_numbers: Tensor, mol_assignmen
     (:173-211): product-block graph, unweighted symmetric-normalised Laplacian with unit diagonal (torch_geometric
     get_laplacian(normalization='sym'), :150-154), eigenvectors 1..k of the ascending spectrum times `signs` (B,max_eig),
     rows of the product shared through the atom-map numbers, zero padded to dim.
-    PARITY UNPINNED against the reference for this function: it needs torch_geometric (and scipy's ARPACK for the
-    non-GPU variant), absent from the container; tests check it through eigenvector properties instead."""
+    Pinned by tests/golden/pos_laplacian.npz: both reference variants run on shims for the three torch_geometric helpers
+    they call (tests/golden/make_golden_r2.py), compared up to the sign / basis freedom of eigenvectors
+    (tests/golden/common.py check_lap_encodings)."""
     B, n = atom_map_numbers.shape
     out = torch.zeros(B, n, dim)
     pos = product_positions(atom_map_numbers, mol_assignments)

@@ -129,3 +129,43 @@ def check_extra(X_extra, y_extra, case, z, E, node_mask, Lap=None, atol=2e-5):
                 lam = float(y_extra[b, 6 + k]) * float(nreal[b])
                 assert abs(float(v.norm()) - 1.0) <= 1e-4
                 assert float((Lap[b] @ v - lam * v).abs().max()) <= 1e-3 * max(1.0, lam), (case, b, k)
+
+
+def check_lap_encodings(out, gold, lap, am, mol, K, atol=5e-3):
+    """Laplacian positional encodings `out` (B,n,dim) against the reference's `gold` (tests/golden/pos_laplacian.npz).
+    Eigenvectors are defined up to a sign and, inside a repeated eigenvalue, up to a basis, and the reference keeps columns
+    1..k of whatever basis its solver returned.  Compared: the zero pattern (padding columns, unmapped rows) exactly; per
+    cluster of equal eigenvalues that lies wholly inside the kept columns and away from the eigenvalue-1 cluster of the
+    isolated non-product nodes, the projector onto the cluster's columns (product rows), which no choice of basis or sign
+    changes; simple eigenvalues additionally column by column up to a sign.  The kept columns at or beyond the eigenvalue-1
+    cluster are arbitrary vectors of that eigenspace in the reference itself (ARPACK / LAPACK basis) and are not compared.
+    Returns (#columns compared, #kept columns whose eigenvalue lies below that cluster)."""
+    out, gold, lap = out.detach().cpu().double(), gold.double(), lap.double()
+    B, n, _ = out.shape
+    done = total = 0
+    for b in range(B):
+        isprod = mol[b] == mol[b].max()
+        k = min(K, int(isprod.sum()))
+        total += int((ev_below := (torch.linalg.eigvalsh(lap[b])[1:k + 1] < 1 - 1e-3)).sum())
+        assert (out[b][:, k:] == 0).all() and (gold[b][:, k:] == 0).all()
+        assert torch.equal((out[b].abs().sum(-1) == 0), (gold[b].abs().sum(-1) == 0)), 'rows without an encoding differ'
+        ev = torch.linalg.eigvalsh(lap[b])
+        c = 0
+        while c < k:
+            lam = float(ev[1 + c])
+            members = ((ev - lam).abs() < 1e-4).nonzero().squeeze(1)
+            lo, hi = int(members.min()), int(members.max())
+            width = hi - (1 + c) + 1
+            if lo >= 1 and hi <= k and abs(lam - 1.0) > 1e-3:
+                cols = slice(lo - 1, hi)
+                Vo, Vg = out[b][isprod][:, cols], gold[b][isprod][:, cols]
+                assert float((Vo @ Vo.T - Vg @ Vg.T).abs().max()) <= atol, (b, lo, hi)
+                if lo == hi:
+                    assert min(float((Vo - Vg).abs().max()), float((Vo + Vg).abs().max())) <= atol, (b, lo)
+                done += hi - lo + 1
+            c += max(width, 1)
+        # rows of mapped reactant atoms repeat their product atom's row (as in gold)
+        rows_equal = (out[b][:, None, :] == out[b][None, :, :]).all(-1)
+        gold_equal = (gold[b][:, None, :] == gold[b][None, :, :]).all(-1)
+        assert torch.equal(rows_equal, gold_equal), 'sharing pattern between nodes differs'
+    return done, total

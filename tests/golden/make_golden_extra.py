@@ -66,7 +66,7 @@ def run_case(name, X, E, nm, info, out, seed):
 
 def gen_pos_encodings():
     """Deterministic positional-encoding variants of the reference's PositionalEmbedding (sinusoidal product index, info-leak,
-    Gaussian rows).  The Laplacian variants need torch_geometric (absent here): parity unpinned, see tests."""
+    Gaussian rows).  The Laplacian variants: make_golden_r2.py gen_pos_laplacian."""
     from diffalign.neuralnet.transformer_model_with_y import PositionalEmbedding as RefPE
     dim = 64
     true = S.make_reaction_batch(5, 48, seed=31)

@@ -1,6 +1,7 @@
 """GPU: positional encodings on the device (csrc/k_posenc.hip through the C-ABI) against the reference's PositionalEmbedding
-outputs (tests/golden/pos_encodings.npz) and, for the Laplacian variant (parity unpinned: torch_geometric is absent from the
-build container), eigenvector properties and the CPU oracle up to a sign."""
+outputs (tests/golden/pos_encodings.npz; the Laplacian variants: tests/golden/pos_laplacian.npz, generated from the reference's
+code on shims for the three torch_geometric helpers it calls, compared up to the sign / basis freedom of eigenvectors), plus
+eigenvector properties and the CPU oracle up to a sign."""
 import pytest
 import torch
 
@@ -27,6 +28,27 @@ def test_deterministic_variants_vs_reference_golden(tag):
     torch.testing.assert_close(pe.matched_positional_encodings_infoleak(am, mol).cpu(), g('infoleak'), atol=2e-6, rtol=0)
     out = pe.matched_positional_encodings_gaussian(am, mol, noise=g('gaussian_noise').to(D))
     assert torch.equal(out.cpu(), g('gaussian'))
+
+
+@pytest.mark.parametrize('variant', ['laplacian', 'laplacian_gpu'])
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_laplacian_encodings_vs_reference_golden(tag, variant):
+    from diffalign_amd.pos_encodings import PositionalEmbedding
+    from diffalign_amd import _lib as L
+    import ctypes as C
+    from tests.golden.common import check_lap_encodings
+    z = load('pos_laplacian')
+    g = lambda k: torch.from_numpy(z[f'{tag}::{k}'])
+    dim, K = int(z['dim']), int(z['K'])
+    E, am, mol = g('E').to(D), g('am').to(D), g('mol').to(D)
+    B, n = am.shape
+    pe = PositionalEmbedding(dim, 0)
+    out = getattr(pe, 'matched_positional_encodings_' + variant)(E, am, mol, K, signs=g(f'{variant}_signs').to(D))
+    Lk = torch.empty(B, n, n, device=D)
+    L.check(L.lib().da_pos_laplacian(L.ptr(E.contiguous()), L.ptr(mol.contiguous()), L.ptr(Lk), C.c_int(B), C.c_int(n), L.stream()), 'lap')
+    torch.testing.assert_close(Lk.cpu(), g(f'{variant}_lap'), atol=1e-6, rtol=0)
+    done, total = check_lap_encodings(out, g(variant), g(f'{variant}_lap'), am.cpu(), mol.cpu(), K)
+    assert done == total and total >= 15, (done, total)
 
 
 def test_laplacian_encodings_properties():

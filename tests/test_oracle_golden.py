@@ -306,3 +306,18 @@ def test_pos_encodings(tag):
     torch.testing.assert_close(O.pos_enc_sinusoidal(am, mol, dim), torch.from_numpy(z[f'{tag}::sinusoidal']), atol=1e-6, rtol=0)
     torch.testing.assert_close(O.pos_enc_infoleak(am, dim), torch.from_numpy(z[f'{tag}::infoleak']), atol=1e-6, rtol=0)
     assert torch.equal(O.pos_enc_gaussian(am, torch.from_numpy(z[f'{tag}::gaussian_noise'])), torch.from_numpy(z[f'{tag}::gaussian']))
+
+
+@pytest.mark.parametrize('variant', ['laplacian', 'laplacian_gpu'])
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_laplacian_pos_encodings_vs_reference(tag, variant):
+    """a13: oracle restatement against the reference's two Laplacian variants (scipy eigsh and torch eigh), generated by
+    tests/golden/make_golden_r2.py on shims for the three torch_geometric helpers (see its docstring)."""
+    from tests.golden.common import check_lap_encodings
+    z = load('pos_laplacian')
+    g = lambda k: torch.from_numpy(z[f'{tag}::{k}'])
+    dim, K = int(z['dim']), int(z['K'])
+    out, laps = O.pos_enc_laplacian(g('E'), g('am'), g('mol'), K, dim, g(f'{variant}_signs'))
+    torch.testing.assert_close(laps, g(f'{variant}_lap'), atol=1e-6, rtol=0)       # the product-block Laplacian itself
+    done, total = check_lap_encodings(out, g(variant), laps, g('am'), g('mol'), K)
+    assert done == total and total >= 15, (done, total)     # every well-defined column was compared
