@@ -20,8 +20,6 @@ class SamplingMixin:
         chain_seeds (B,) int64: per-chain counter-based noise (helpers.counter_exp_noise) -- every chain's draws depend on its
         own seed only, so sharded runs give the same samples under any rank layout (diffalign_amd/distributed.py)."""
         assert data is not None, 'diffalign_amd samples conditionally: `data` (the dense condition) is required'
-        if self.cfg.diffusion.classifier_free_guidance:
-            raise NotImplementedError('classifier-free guidance is off in both align_* experiments and is not built')
         assert self.cfg.test.with_denoising
         dense_data = data
         device = dense_data.X.device if device is None else device
@@ -75,30 +73,44 @@ class SamplingMixin:
         sample_chains, prob_s_chains, pred_0_chains = [], [], []
         temps = (float(self.cfg.diffusion.temperature_scaling_node), float(self.cfg.diffusion.temperature_scaling_edge))
         tm = self.transition_model_eval
+        guided = bool(getattr(self.cfg.diffusion, 'classifier_free_guidance', False))
+        if guided:                                                         # what the unconditional forward may see (sampling.py:90-95)
+            cond_free = graph.get_node_masks(dense_data, self.dataset_info.atom_decoder, self.dataset_info.bond_decoder,
+                                             self.cfg.diffusion.mask_nodes, self.cfg.diffusion.mask_edges, include_supernode=False)
         log_every_t = int(getattr(getattr(self.cfg, 'train', None), 'log_every_t', 1) or 1)
         for t_int in range(T_eval, 0, -1):
             t_array = torch.full((B, 1), t_int, dtype=torch.long, device=device)
             z_t.y = t_array.float() * eval_step_size                       # raw train-scale step index (sampling.py:76)
             s_int = t_int - 1
             record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)
-            if not record:                                                 # the whole step as one call (fused where the model allows)
+            if not record and not guided:                                  # the whole step as one call (fused where the model allows)
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
                                                 orig=dense_data, node_masks=masks, **nz(step=True))
                 z_t.X, z_t.E = zsX, zsE
                 z_t = fix(z_t)
                 continue
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)
+            if record or guided:
+                pX, pE, _, _ = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
+                                                        tm.get_Qt_bar(t_array), temperature=temps, want_prob=True, want_sample=False)
+            if guided:
+                pX, pE = self._guide(z_t, t_array, pX, pE, cond_free)
             if record:                                                                   # sampling.py:120-161 (plotting chains)
                 sample_chains.append((t_int, z_t.get_new_object().mask(z_t.node_mask, collapse=True)))
                 p0 = pred.get_new_object(X=torch.softmax(pred.X, -1), E=torch.softmax(pred.E, -1))
                 p0.X[..., -1] = 0.                                         # SuNo predictions ignored (sampling.py:125-126)
                 p0.X /= p0.X.sum(-1, keepdim=True)
-                pX, pE, _, _ = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
-                                                        tm.get_Qt_bar(t_array), temperature=temps, want_prob=True, want_sample=False)
                 for chain, obj in ((pred_0_chains, p0), (prob_s_chains, z_t.get_new_object(X=pX, E=pE))):
                     obj = graph.apply_mask(orig=dense_data, z_t=obj, atom_decoder=self.dataset_info.atom_decoder,
                                            bond_decoder=self.dataset_info.bond_decoder, node_masks=masks)
                     chain.append((s_int, fix(obj)))
+            if guided:                                                     # draw from the guided p(z_s | z_t) (sampling.py:165-174)
+                z_s = helpers.sample_discrete_features(z_t.get_new_object(X=pX, E=pE), noise=nz())
+                z_s = graph.apply_mask(orig=dense_data, z_t=z_s, atom_decoder=self.dataset_info.atom_decoder,
+                                       bond_decoder=self.dataset_info.bond_decoder, node_masks=masks)
+                z_t.X, z_t.E = z_s.X, z_s.E
+                z_t = fix(z_t)
+                continue
             _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
                                                       tm.get_Qt_bar(t_array), temperature=temps, noise=nz(),
                                                       orig=dense_data, node_masks=masks)
@@ -111,3 +123,28 @@ class SamplingMixin:
         if get_chains:
             return (z_t.mask(z_t.node_mask, collapse=True), sample_chains, prob_s_chains, pred_0_chains)
         return z_t
+
+    def _guide(self, z_t, t_array, pX, pE, cond_free):
+        """Classifier-free guidance (sampling.py:88-113): a second forward on z_t with the condition zeroed (everything apply_mask keeps
+        fixed except the supernode; with classifier_free_full_unconditioning also the atom-map numbers) and the positional encodings
+        switched off gives p_u(z_s | z_t); the step is drawn from softmax((1 + w) log p - w log p_u).  As in the reference the
+        unconditional posterior uses the TRAINING transition model and no temperature."""
+        d = self.cfg.diffusion
+        B = z_t.X.shape[0]
+        free_x, free_e = cond_free
+        pair = free_e[:, :, None] & free_e[:, None, :]
+        am = z_t.atom_map_numbers
+        if d.classifier_free_full_unconditioning and self.cfg.neuralnet.architecture == 'with_y_atommap_number_pos_enc':
+            am = torch.zeros_like(am)                                                                         # :100-101
+        z_nc = z_t.get_new_object(X=z_t.X * free_x[:, :, None].float(), E=z_t.E * pair[..., None].float(), atom_map_numbers=am)
+        pred_u = self.forward(z_t=z_nc, use_pos_encoding_if_applicable=torch.zeros(B, dtype=torch.bool, device=z_t.X.device))   # :105
+        tm = self.transition_model
+        uX, uE, _, _ = helpers.posterior_sample(pred_u.X, pred_u.E, z_t, tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1),
+                                                tm.get_Qt_bar(t_array), want_prob=True, want_sample=False)        # :106-107
+        w = float(d.classifier_free_guidance_weight)
+        eps = 1e-30
+        gX = torch.softmax((1 + w) * torch.log(pX + eps) - w * torch.log(uX + eps), -1)                      # :110-111
+        gE = torch.softmax((1 + w) * torch.log(pE + eps) - w * torch.log(uE + eps), -1)
+        gX[gX < 1e-28] = 0.                                                                                   # :112-113
+        gE[gE < 1e-28] = 0.
+        return gX, gE

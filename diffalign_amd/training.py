@@ -40,13 +40,13 @@ class TrainingMixin:
     """Needs from the host object: cfg, T, transition_model, dataset_info, model, forward, apply_noise, elbo_batch_quick."""
 
     def training_step(self, data: PlaceHolder, i: int = 0, device=None, t_int: Optional[torch.Tensor] = None, noise=None,
-                      z_t: Optional[PlaceHolder] = None, pos_encodings=None, want_terms: bool = True):
+                      z_t: Optional[PlaceHolder] = None, pos_encodings=None, want_terms: bool = True,
+                      uncond_draw: Optional[torch.Tensor] = None):
         """diffusion_abstract.py:134-225.  `data`: dense PlaceHolder on the device (the reference's graph.to_dense is the data
         loader's side).  Returns (loss_X, loss_E, loss) as the reference does -- values, without an autograd graph; the
-        context the backward needs stays in self._train_ctx.  t_int / noise / z_t fix the reference's random draws."""
+        context the backward needs stays in self._train_ctx.  t_int / noise / z_t fix the reference's random draws;
+        uncond_draw (B,) in [0,1) stands for the `torch.rand(bs)` of classifier-free guidance (:163)."""
         d = self.cfg.diffusion
-        if getattr(d, 'classifier_free_guidance', False):
-            raise NotImplementedError('classifier-free guidance is off in both align_* experiments and is not built')
         dense_data = data
         B = dense_data.X.shape[0]
         dev = dense_data.X.device
@@ -61,12 +61,16 @@ class TrainingMixin:
         z_keep = z_t.get_new_object()                                                                         # :144
         if not d.diffuse_edges: z_t.E = dense_data.E.clone()
         if not d.diffuse_nodes: z_t.X = dense_data.X.clone()
+        use_pos = None
+        if getattr(d, 'classifier_free_guidance', False):
+            z_t, use_pos = self._drop_condition(dense_data, z_t, uncond_draw)                                 # :152-179
         loss_kind = getattr(getattr(self.cfg, 'train', None), 'loss', 'ce')
         if self.model.training and torch.is_grad_enabled():
             # the differentiable path: fp32 training forward under autograd (train_forward.py), the objective as one
             # autograd.Function whose backward is da_ce_grad / da_vb_grad; `loss.backward()` then fills every parameter's .grad
             from .autograd_ops import DiffusionLoss
-            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings)   # pos_encodings: precomputed (they depend on the condition only)
+            pred = self.forward(z_t=z_t, pos_encodings=pos_encodings,   # pos_encodings: precomputed (they depend on the condition only)
+                                use_pos_encoding_if_applicable=use_pos)
             loss = DiffusionLoss.apply(pred.X, pred.E, self, dense_data, z_keep, node_masks, loss_kind)
             self._train_ctx = None
             loss_X = loss_E = torch.zeros((1,))
@@ -80,7 +84,7 @@ class TrainingMixin:
         self.model._saved = saved
         try:
             with torch.no_grad():
-                pred = self.forward(z_t=z_t)                                                                  # :181-185
+                pred = self.forward(z_t=z_t, use_pos_encoding_if_applicable=use_pos)                          # :181-185
         finally:
             self.model._saved = None
         lam = d.lambda_train[0]
@@ -101,6 +105,33 @@ class TrainingMixin:
             raise ValueError(f'Unknown loss {loss_kind}')
         self._train_ctx = dict(pred=pred, data=dense_data, node_masks=node_masks, saved=saved, loss_kind=loss_kind, lam=lam)
         return loss_X, loss_E, loss
+
+    def _drop_condition(self, dense_data: PlaceHolder, z_t: PlaceHolder, uncond_draw: Optional[torch.Tensor]):
+        """Classifier-free guidance at training time (diffusion_abstract.py:152-179): graphs whose draw falls below
+        classifier_free_uncond_prob lose their condition -- everything apply_mask would keep fixed except the supernode is
+        zeroed in z_t and their positional encodings are switched off.  classifier_free_drop_within_batch=False is the older rule:
+        the whole batch follows graph 0's draw.  With classifier_free_full_unconditioning the reference clears the atom-map
+        numbers of the graphs that KEEP their condition (:178, its own TODO); that is reproduced as written.
+        Returns (z_t, use_pos_encoding_if_applicable)."""
+        d = self.cfg.diffusion
+        B = z_t.X.shape[0]
+        dev = z_t.X.device
+        free_x, free_e = graph.get_node_masks(dense_data, self.dataset_info.atom_decoder, self.dataset_info.bond_decoder, d.mask_nodes,
+                                              d.mask_edges, include_supernode=False)                         # :155-160
+        r = torch.rand(B) if uncond_draw is None else uncond_draw                                             # :163
+        unconditional = (r.to(dev) < d.classifier_free_uncond_prob)                                           # :164
+        if d.classifier_free_drop_within_batch:
+            keep_all = ~unconditional                                                                         # :167-169
+        else:
+            keep_all = (~unconditional[0:1]).expand(B)                                                        # :171-173
+        free_x = free_x | keep_all[:, None]
+        free_e = free_e | keep_all[:, None]
+        am = z_t.atom_map_numbers
+        if d.classifier_free_full_unconditioning and self.cfg.neuralnet.architecture == 'with_y_atommap_number_pos_enc':
+            am = am * unconditional[:, None].to(am.dtype)                                                     # :176-178
+        pair = free_e[:, :, None] & free_e[:, None, :]
+        z_t = z_t.get_new_object(X=z_t.X * free_x[:, :, None].float(), E=z_t.E * pair[..., None].float(), atom_map_numbers=am)  # :179
+        return z_t, ~unconditional
 
     def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None, pos_encodings=None):
         """training/helpers.py:130-142 for one batch: zero_grad, training_step, backward, gradient all-reduce over `group` (data

@@ -605,11 +605,22 @@ def counter_exp_noise(seeds: Tensor, call: int, n: int, kx: int, ke: int) -> Tup
     return stream(2 * call, n * kx).reshape(B, n, kx), stream(2 * call + 1, n * n * ke).reshape(B, n, n, ke)
 
 
+def guided_probs(pX, pE, uX, uE, w: float, eps: float = 1e-30):
+    """diffusion/sampling.py:108-113: classifier-free guidance on the two posteriors."""
+    gX = torch.softmax((1 + w) * torch.log(pX + eps) - w * torch.log(uX + eps), -1)
+    gE = torch.softmax((1 + w) * torch.log(pE + eps) - w * torch.log(uE + eps), -1)
+    gX[gX < 1e-28] = 0.
+    gE[gE < 1e-28] = 0.
+    return gX, gE
+
+
 def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tensor], T: int, T_eval: int, mask_mode: str,
-                 suno_idx: int, noise_fn, temp=(1.0, 1.0), node_idx=None, edge_idx=None):
+                 suno_idx: int, noise_fn, temp=(1.0, 1.0), node_idx=None, edge_idx=None, guidance=None):
     """forward_fn(zX, zE, y) -> (logits_X, logits_E).  noise_fn(call_index, shape) -> Exp(1) noise; calls are numbered
     in the reference's multinomial order: limit draw (X, E), then per step (X, E).  node_idx / edge_idx: inpainting lists
-    (sampling.py:42-45,175-178: the listed nodes / edges are copied back from the condition after every draw)."""
+    (sampling.py:42-45,175-178: the listed nodes / edges are copied back from the condition after every draw).
+    guidance = dict(w=..., forward_uncond=fn(zX, zE, y) -> logits, tabs_train=...): classifier-free guidance (sampling.py:88-113);
+    forward_uncond sees z_t with the condition (everything fixed except the supernode) zeroed."""
     X0, E0, nm = true['X'], true['E'], true['node_mask']
     B, n, Kx = X0.shape
     Ke = E0.shape[-1]
@@ -632,7 +643,17 @@ def sample_chain(forward_fn, true: Dict[str, Tensor], tabs_eval: Dict[str, Tenso
         qX = noise_fn(c, (B * n, Kx)).reshape(B, n, Kx)
         qE = noise_fn(c + 1, (B * n * n, Ke)).reshape(B, n, n, Ke)
         c += 2
-        _, _, zX, zE = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
+        if guidance is None:
+            _, _, zX, zE = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
+        else:
+            pX, pE, _, _ = reverse_step(lX, lE, zX, zE, nm, tabs_eval, t, X0, E0, mx, me, qX, qE, temp[0], temp[1])
+            fx, fe = free_masks(X0, nm, true.get('atom_map_numbers'), mask_mode, suno_idx, include_supernode=False)
+            MX, ME = expand_masks(fx, fe, Kx, Ke)
+            uX, uE = guidance['forward_uncond'](zX * MX, zE * ME, y)
+            uX, uE, _, _ = reverse_step(uX, uE, zX, zE, nm, guidance['tabs_train'], t, X0, E0, mx, me, qX, qE)
+            gX, gE = guided_probs(pX, pE, uX, uE, guidance['w'])
+            Xs, Es = sample_discrete(gX, gE, nm, qX, qE)
+            zX, zE = apply_mask(X0, E0, *one_hot_pair(Xs, Es, Kx, Ke), mx, me)
         zX, zE = fix(zX, zE)
     return zX, zE
 

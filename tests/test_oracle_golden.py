@@ -321,3 +321,73 @@ def test_laplacian_pos_encodings_vs_reference(tag, variant):
     torch.testing.assert_close(laps, g(f'{variant}_lap'), atol=1e-6, rtol=0)       # the product-block Laplacian itself
     done, total = check_lap_encodings(out, g(variant), laps, g('am'), g('mol'), K)
     assert done == total and total >= 15, (done, total)     # every well-defined column was compared
+
+
+CFG_NODES, CFG_EDGES = [[0, 1], [], [], [2]], [[[0, 1]], [], [], []]
+
+
+def _uncond_forward(z, sd, true, full):
+    """The denoiser as classifier-free guidance calls it without a condition: positional encodings off, and with
+    classifier_free_full_unconditioning the atom-map numbers cleared."""
+    am = torch.zeros_like(true['atom_map_numbers']) if full else true['atom_map_numbers']
+    pos0 = torch.zeros(*true['node_mask'].shape, 64)
+
+    def fwd(zX, zE, y):
+        r = O.denoiser_forward(sd, zX, zE, y, true['node_mask'], int(z['n_layers']), int(z['n_head']), (KX, KE, 1), am, pos0,
+                               true['mol_assignments'], True)
+        return r[0], r[1]
+    return fwd
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_classifier_free_guidance_chain(full):
+    """sample_one_batch with classifier_free_guidance (sampling.py:88-113), weight 0.7, inpainting lists: bit for bit."""
+    zc = load('cfg_tiny')
+    z, sd, true, fwd = _tiny_setup()
+    assert np.array_equal(zc['true_X'], z['true_X'])
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    g = dict(w=float(zc['weight']), forward_uncond=_uncond_forward(z, sd, true, full), tabs_train=tabs)
+    zX, zE = O.sample_chain(fwd, true, tabs, 10, 10, 'product_and_sn', 28, lambda c, shp: counter_noise(shp, c), node_idx=CFG_NODES,
+                            edge_idx=CFG_EDGES, guidance=g)
+    assert np.array_equal(zX.argmax(-1).numpy(), zc[f'chain_full{int(full)}_X'])
+    assert np.array_equal(zE.argmax(-1).numpy(), zc[f'chain_full{int(full)}_E'])
+
+
+def oracle_cfg_training(zc, z, sd, true, within, full):
+    """training_step with classifier-free guidance (diffusion_abstract.py:152-185) restated on the oracle's pieces: returns
+    (loss, z_t X, z_t E, use_pos, atom maps) for the reference's recorded t and r."""
+    from diffalign_amd import synthetic as S
+    t, r = T(zc['train_t']).float(), T(zc['train_r'])
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    nm = true['node_mask']
+    B, n = nm.shape
+    pX, pE = O.noise_probs(true['X'], true['E'], nm, tabs['Qtb_x'][t[:, 0].long()], tabs['Qtb_e'][t[:, 0].long()])
+    Xs, Es = O.sample_discrete(pX, pE, nm, counter_noise((B * n, KX), 7000).reshape(B, n, KX),
+                               counter_noise((B * n * n, KE), 7001).reshape(B, n, n, KE))
+    mx, me = O.free_masks(true['X'], nm, true['atom_map_numbers'], 'product_and_sn', 28)
+    ztX, ztE = O.apply_mask(true['X'], true['E'], *O.one_hot_pair(Xs, Es, KX, KE), mx, me)
+    fx, fe = O.free_masks(true['X'], nm, true['atom_map_numbers'], 'product_and_sn', 28, include_supernode=False)
+    uncond = r < 0.1
+    keep = ~uncond if within else (~uncond[0:1]).expand(B)
+    MX, ME = O.expand_masks(fx | keep[:, None], fe | keep[:, None], KX, KE)
+    am = true['atom_map_numbers'] * uncond[:, None].long() if full else true['atom_map_numbers']
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=am), 64, seed=73) * (~uncond)[:, None, None].float()
+    inX, inE = ztX * MX, ztE * ME
+    lX, lE, _ = O.denoiser_forward(sd, inX, inE, t, nm, int(z['n_layers']), int(z['n_head']), (KX, KE, 1), am, pos, true['mol_assignments'], True)
+    return O.ce_loss(lX, lE, true['X'], true['E'], mx, me, 5.0)[2], inX, inE, ~uncond, am
+
+
+@pytest.mark.parametrize('within,full', [(True, False), (True, True), (False, False), (False, True)])
+def test_classifier_free_guidance_training_step(within, full):
+    zc = load('cfg_tiny')
+    z, sd, true, _ = _tiny_setup()
+    sd = {k: v.clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    loss, inX, inE, use, am = oracle_cfg_training(zc, z, sd, true, within, full)
+    k = f'train_w{int(within)}_f{int(full)}_'
+    close(inX, zc[k + 'zt_X'], 0); close(inE, zc[k + 'zt_E'], 0)
+    assert np.array_equal(use.numpy(), zc[k + 'use']) and np.array_equal((am == 0).numpy(), zc[k + 'am_zero'])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(zc[k + 'loss'])) <= 2e-4 * abs(float(zc[k + 'loss']))
+    for pn in ('mlp_in_E.0.weight', 'tf_layers.1.linE2.weight', 'mlp_out_X.2.weight', 'skip_scaling'):
+        want, got = float(zc[k + 'gnorm::' + pn]), float(sd[pn].grad.norm())
+        assert abs(got - want) <= 1e-3 * abs(want) + 1e-6, (pn, got, want)
