@@ -350,11 +350,12 @@ def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n,
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
-                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None):
+                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None, edge_skip_uniform=False):
     """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
     `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py).
     `step`: the reverse step fused behind the output stage (helpers.ReverseStep.ctx: z_t, transition tables, noise, masks): the edge
-    half is drawn inside the output kernel (da_edge_out_sample) and the edge logits are not materialised (Eo is None); the node half runs behind the node output path.  The drawn state lands in step['zs_X'], step['zs_E']."""
+    half is drawn inside the output kernel (da_edge_out_sample) and the edge logits are not materialised (Eo is None); the node half runs behind the node output path.  The drawn state lands in step['zs_X'], step['zs_E'].
+    `edge_skip_uniform`: input_alignment=True scales the whole edge skip term by skip_scaling_2 (transformer_model_with_y.py:702-704)."""
     dev = X.device
     B, n = X.shape[:2]
     R = B * n
@@ -465,6 +466,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     lin = torch.empty(R, pm.kx, device=dev)
     Xo = torch.empty(B, n, pm.kx, device=dev)
     s1, s2 = pm.skip if use_skip else (None, None)
+    es1 = s2 if edge_skip_uniform else s1            # scale of the mapped pairs' edge skip term
 
     def node_output_path():
         _linear(Xh, pm.dx, pm.out_X[0], pm.out_X[1], None, h1, pm.hx, R, pm.hx, pm.dx, True)
@@ -491,21 +493,21 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     Eo = torch.empty(B, n, n, pm.ke, device=dev) if step is None else None
     if step is not None:
         c = step
-        L.check(lib.da_edge_out_sample(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2),
+        L.check(lib.da_edge_out_sample(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2),
                                        L.ptr(c['zt_E']), L.ptr(nm), L.ptr(c['Qt_e']), L.ptr(c['Qsb_e']), L.ptr(c['Qtb_e']),
                                        C.c_float(c['temp'][1]), L.ptr(c['noise_E']), L.ptr(c['seeds']),
                                        int(c['call']), L.ptr(c['orig_E']), L.ptr(c['me']), L.ptr(c['zs_E']), _i(B), _i(n), _i(pm.de), _i(pm.he),
                                        _i(pm.ke), S), 'da_edge_out_sample')
     elif EDGE_OUT == 'tiles':
-        L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo),
+        L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo),
                                       _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')
     elif EDGE_OUT == '2pass':
         G = torch.empty(B, n, n, 8, device=dev)
         L.check(lib.da_edge_out_g(L.ptr(Eh), L.ptr(pm.out_E), L.ptr(G), _i(B), _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_out_g')
-        L.check(lib.da_edge_out_finish(L.ptr(G), L.ptr(E), _i(pm.de_in), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B), _i(n),
+        L.check(lib.da_edge_out_finish(L.ptr(G), L.ptr(E), _i(pm.de_in), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo), _i(B), _i(n),
                                        _i(pm.ke), S), 'da_edge_out_finish')
     else:
-        L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(s1), L.ptr(s2), L.ptr(Eo), _i(B),
+        L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo), _i(B),
                                 _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out')
     if xout_done is not None:
         main.wait_event(xout_done)

@@ -43,12 +43,34 @@ def _layer(layer, X, E, y, nm_u8, xm, em, training):
     return X, E, y
 
 
+def aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke):
+    """transformer_model_with_y.py:506-555 (alignment 'correct') + :633-645 as gathers: for every reactant-side node r with an atom-map
+    number, the input features of the product node p(r) carrying the same number.  Returns (X_al (B,n,kx): X[p(r), :kx] on mapped
+    rows, else 0;  E_al (B,n,n,ke): E[p(r1), p(r2), :ke] on mapped pairs, else one-hot class 0;  pair (B,n,n,1) bool)."""
+    B, n = X.shape[:2]
+    src = torch.empty(B, n, dtype=torch.int32, device=X.device)
+    L.check(L.lib().da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
+                                   L.ptr(src), B, n, L.stream()), 'da_align_index')
+    sel = src >= 0
+    idx = src.clamp_min(0).long()
+    X_al = torch.gather(X[..., :kx], 1, idx[:, :, None].expand(-1, -1, kx)) * sel[:, :, None]
+    pair = (sel[:, :, None] & sel[:, None, :])[..., None]
+    bi = torch.arange(B, device=X.device)[:, None, None]
+    first = (torch.arange(ke, device=X.device) == 0).float()          # class 0; built on the device (graph-capturable)
+    E_al = E[bi, idx[:, :, None], idx[:, None, :]][..., :ke] * pair + first * (~pair)
+    return X_al, E_al, pair
+
+
 def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None):
     """Differentiable forward of the denoiser module `m`; returns (X logits, E logits, y) like the module's forward."""
     if not X.is_cuda:
         raise L.DiffAlignHipError('denoiser inputs must be on a HIP device (no CPU fallback)')
     X, E, y = X.float(), E.float(), y.float()
     B, n = X.shape[:2]
+    X_al = E_al = None
+    if getattr(m, 'input_alignment', False):                             # :630-647: the aligned product features as extra input channels
+        X_al, E_al, _ = aligned_product_features(X, E, atom_map_numbers, mol_assignments, m.out_dim_X, m.out_dim_E)
+        X, E = torch.cat([X, X_al], -1), torch.cat([E, E_al], -1)
     nm_u8 = L.as_u8(node_mask)
     xm = node_mask[:, :, None].float()
     em = xm[:, :, None, :] * xm[:, None, :, :]
@@ -66,17 +88,13 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
     Eo = 0.5 * (Eo + Eo.transpose(1, 2))
     yo = yh[..., :ky] + y[..., :ky]
     if getattr(m, 'p_to_r_skip_connection', False):
-        # transformer_model_with_y.py:686-704 (alignment 'correct') as a gather: mapped reactant-side nodes / pairs take s1 times the
-        # product's input features, every other pair s2 on class 0
-        src = torch.empty(B, n, dtype=torch.int32, device=X.device)
-        L.check(L.lib().da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
-                                       L.ptr(src), B, n, L.stream()), 'da_align_index')
-        sel = src >= 0
-        idx = src.clamp_min(0).long()
-        Xo = Xo + m.skip_scaling * torch.gather(X[..., :kx], 1, idx[:, :, None].expand(-1, -1, kx)) * sel[:, :, None]
-        pair = (sel[:, :, None] & sel[:, None, :])[..., None]
-        bi = torch.arange(B, device=X.device)[:, None, None]
-        Eg = E[bi, idx[:, :, None], idx[:, None, :]][..., :ke]
-        first = (torch.arange(ke, device=X.device) == 0).float()          # class 0; built on the device (graph-capturable)
-        Eo = Eo + m.skip_scaling * Eg * pair + m.skip_scaling_2 * first * (~pair)
+        # transformer_model_with_y.py:686-704 as a gather: mapped reactant-side nodes / pairs take s1 times the product's input features,
+        # every other pair s2 on class 0; with input_alignment the reference reuses the concatenated tensors and scales ALL of the edge
+        # part by s2 (:702-704)
+        if X_al is None:
+            X_al, E_al, pair = aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke)
+            Eo = Eo + torch.where(pair, m.skip_scaling * E_al, m.skip_scaling_2 * E_al)
+        else:
+            Eo = Eo + m.skip_scaling_2 * E_al
+        Xo = Xo + m.skip_scaling * X_al
     return Xo, Eo, yo

@@ -79,9 +79,11 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
                  act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), pos_emb_permutations: int = 0, improved=False, dropout=0.1,
                  p_to_r_skip_connection=False, p_to_r_init=10., alignment_type='old', input_alignment=False):
         super().__init__()
-        if input_alignment:
-            raise NotImplementedError('input_alignment=True is off in both align_* experiments and is not built')
-        if p_to_r_skip_connection and alignment_type != 'correct':
+        if input_alignment:                                              # :575-580: the aligned product features widen both inputs
+            input_dims = dict(input_dims)
+            input_dims['X'] += output_dims['X']
+            input_dims['E'] += output_dims['E']
+        if (p_to_r_skip_connection or input_alignment) and alignment_type != 'correct':
             raise NotImplementedError("alignment_type='old' is not built (align_absorbing uses 'correct')")
         self.pos_emb_permutations = pos_emb_permutations
         self.p_to_r_skip_connection = p_to_r_skip_connection
@@ -100,7 +102,12 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments) + (node_mask,)
         pm = self._pack(X.device)
+        if self.input_alignment:                                         # :630-647
+            from .train_forward import aligned_product_features
+            X_al, E_al, _ = aligned_product_features(X.float(), E.float(), atom_map_numbers, mol_assignments, self.out_dim_X, self.out_dim_E)
+            X, E = torch.cat([X.float(), X_al], -1), torch.cat([E.float(), E_al], -1)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
-                                          use_skip=self.p_to_r_skip_connection, save=self._saved, step=step)
+                                          use_skip=self.p_to_r_skip_connection, save=self._saved, step=step,
+                                          edge_skip_uniform=self.input_alignment)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask

@@ -393,13 +393,31 @@ def p_to_r_skip(X_o, E_o, X_in, E_in, src: Tensor, s1, s2, Kx: int, Ke: int):
     return X_o, E_o
 
 
+def aligned_inputs(X_in, E_in, src: Tensor, Kx: int, Ke: int):
+    """transformer_model_with_y.py:630-645 (input_alignment): X_to_concatenate / E_to_concatenate."""
+    B, n = src.shape
+    Xc, Ec = torch.zeros(B, n, Kx), torch.zeros(B, n, n, Ke)
+    onehot0 = torch.zeros(Ke); onehot0[0] = 1.
+    for b in range(B):
+        sel = src[b] >= 0
+        idx = src[b][sel]
+        Xc[b, sel] = X_in[b, idx, :Kx]
+        pair = sel[:, None] & sel[None, :]
+        Ec[b][pair] = E_in[b, :, :, :Ke][idx][:, idx].reshape(-1, Ke)
+        Ec[b][~pair] = onehot0
+    return Xc, Ec
+
+
 def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n_head: int,
                      out_dims: Tuple[int, int, int], atom_map_numbers=None, pos_encodings=None,
-                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = ''):
+                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = '', input_alignment=False):
     """transformer_model_with_y.py:620-713 (atom-map variant when pos_encodings is given) and
     :74-111 (plain GraphTransformerWithY).  Returns un-masked logits (X, E, y)."""
     Kx, Ke, Ky = out_dims
     B, n = X.shape[:2]
+    if input_alignment:
+        Xc, Ec = aligned_inputs(X, E, align_index(atom_map_numbers, mol_assignments), Kx, Ke)
+        X, E = torch.cat([X, Xc], -1), torch.cat([E, Ec], -1)
     X_in, E_in = X, E
     def mlp_in(name, t):
         return F.relu(_lin(sd, f'{prefix}{name}.2', F.relu(_lin(sd, f'{prefix}{name}.0', t))))
@@ -416,7 +434,10 @@ def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n
     Eo = Eo * (~torch.eye(n, dtype=torch.bool))[None, :, :, None]
     yo = yh[..., :Ky] + y[..., :Ky]
     Eo = 0.5 * (Eo + Eo.transpose(1, 2))
-    if p_to_r_skip_connection:
+    if p_to_r_skip_connection and input_alignment:              # :702-704: the concatenated tensors again, ALL of the edge part times s2
+        Xo = Xo + Xc * sd[prefix + 'skip_scaling']
+        Eo = Eo + Ec * sd[prefix + 'skip_scaling_2']
+    elif p_to_r_skip_connection:
         src = align_index(atom_map_numbers, mol_assignments)
         Xo, Eo = p_to_r_skip(Xo, Eo, X_in, E_in, src, sd[prefix + 'skip_scaling'], sd[prefix + 'skip_scaling_2'], Kx, Ke)
     return Xo, Eo, yo

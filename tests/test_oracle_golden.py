@@ -112,6 +112,27 @@ def test_model_tiny_all_variants():
     close(r[0], z['am_skip_X'], 5e-5); close(r[1], z['am_skip_E'], 5e-5); close(r[2], z['am_skip_y'], 5e-5)
 
 
+def inalign_weights(z):
+    """Weights of tests/golden/model_inalign.npz: the seeded initialiser on the recorded shapes (skip scalings 0.7 / 1.3)."""
+    import ast
+    from tests.golden.common import init_state_dict
+    sd = init_state_dict({str(k): ast.literal_eval(str(s)) for k, s in zip(z['keys'], z['shapes'])}, seed=45)
+    sd['skip_scaling'] = torch.tensor([0.7]); sd['skip_scaling_2'] = torch.tensor([1.3])
+    return sd
+
+
+def test_model_input_alignment():
+    """GraphTransformerWithYAtomMapPosEmb(input_alignment=True), with and without the skip connection (:575-580, 630-647, 702-704)."""
+    z = load('model_inalign')
+    sd = inalign_weights(z)
+    assert sd['mlp_in_X.0.weight'].shape[1] == 2 * KX + 8 and sd['mlp_in_E.0.weight'].shape[1] == 2 * KE
+    X, E, y, nm, am, pos, mol = _model_inputs(z)
+    L, H = int(z['n_layers']), int(z['n_head'])
+    for tag, skip in (('noskip', False), ('skip', True)):
+        r = O.denoiser_forward(sd, X, E, y, nm, L, H, (KX, KE, 1), am, pos, mol, skip, input_alignment=True)
+        close(r[0], z[f'{tag}_X'], 5e-5); close(r[1], z[f'{tag}_E'], 5e-5); close(r[2], z[f'{tag}_y'], 5e-5)
+
+
 def test_model_full_dims_one_layer():
     from tests.golden.common import init_state_dict
     import ast
