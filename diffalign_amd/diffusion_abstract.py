@@ -56,8 +56,10 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                 p_to_r_init=nn_.p_to_r_init, alignment_type=nn_.alignment_type, input_alignment=nn_.input_alignment)
         else:
             raise ValueError(f'Unknown architecture: {nn_.architecture}')
-        if cfg.neuralnet.use_ema:
-            raise NotImplementedError('EMA is off in both align_* experiments (configs/neuralnet/transformer.yaml:2)')
+        self.ema = None
+        if cfg.neuralnet.use_ema:                                                                       # :94-97
+            from .ema import EMA
+            self.ema = EMA(self.model, beta=cfg.neuralnet.ema_decay, power=1)
         steps = [cfg.diffusion.diffusion_steps, cfg.diffusion.diffusion_steps_eval]
         tr = cfg.diffusion.transition
         if tr == 'uniform':
@@ -140,7 +142,7 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
         Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
-        if self.model.supports_fused_step() and not self.model._differentiable() and not want_logits:
+        if self._net().supports_fused_step() and not self._net()._differentiable() and not want_logits:
             ctx = helpers.reverse_step_ctx(z_t, Qt, Qsb, Qtb, temperature, noise, chain_seeds, call, orig, node_masks, generator)
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings, step=ctx)
             return ctx['zs_X'], ctx['zs_E'], pred
@@ -151,6 +153,10 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, z_t, Qt, Qsb, Qtb, temperature=temperature, noise=noise, orig=orig,
                                                   node_masks=node_masks, generator=generator)
         return zsX, zsE, pred
+
+    def _net(self):
+        """The denoiser forward() runs: the EMA copy outside training when cfg.neuralnet.use_ema (:333-339), else the model."""
+        return self.ema.ema_model if (self.ema is not None and not self.training) else self.model
 
     def forward(self, z_t, use_pos_encoding_if_applicable=None, pos_encodings=None, step=None):
         """diffusion_abstract.py:293-348 (denoiser='neuralnet').  The reference's random relabelling of atom-map
@@ -165,9 +171,9 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                 pos_encodings = self.get_pos_encodings(z_t)
             if use_pos_encoding_if_applicable is not None:
                 pos_encodings = pos_encodings * use_pos_encoding_if_applicable[:, None, None].float()
-            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask, z_in.atom_map_numbers, pos_encodings,
-                                            z_in.mol_assignments, **({'step': step} if step is not None else {}))
+            X, E, y, node_mask = self._net()(z_in.X, z_in.E, z_in.y, z_in.node_mask, z_in.atom_map_numbers, pos_encodings,
+                                             z_in.mol_assignments, **({'step': step} if step is not None else {}))
         else:
-            X, E, y, node_mask = self.model(z_in.X, z_in.E, z_in.y, z_in.node_mask, **({'step': step} if step is not None else {}))
+            X, E, y, node_mask = self._net()(z_in.X, z_in.E, z_in.y, z_in.node_mask, **({'step': step} if step is not None else {}))
         return PlaceHolder(X=X, E=E, y=y, node_mask=node_mask, atom_map_numbers=z_t.atom_map_numbers,
                            mol_assignments=z_t.mol_assignments)

@@ -83,11 +83,11 @@ class GraphedTrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):                          # settles allocator pools, workspaces and lazily built tables
-                model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos)
+                model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos, update_ema=False)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos)
+            self.loss = model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos, update_ema=False)
 
     def __call__(self, data: PlaceHolder) -> torch.Tensor:
         """One optimisation step on `data` (same shapes as the example).  Returns the (static) loss tensor of this step."""
@@ -101,4 +101,6 @@ class GraphedTrainStep:
         self.graph.replay()
         self.opt.steps += 1
         L.weights_epoch += 1                                 # the bf16 inference path re-packs on its next call
+        if getattr(self.model, 'ema', None) is not None:     # outside the graph: the decay schedule is host state
+            self.model.ema.update()
         return self.loss

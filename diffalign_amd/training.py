@@ -81,12 +81,13 @@ class TrainingMixin:
                     loss_X, loss_E = -rX[mx], -rE[me[:, :, None] & me[:, None, :]]
             return loss_X, loss_E, loss
         saved: Dict[str, torch.Tensor] = {}
-        self.model._saved = saved
+        net = self._net() if hasattr(self, '_net') else self.model
+        net._saved = saved
         try:
             with torch.no_grad():
                 pred = self.forward(z_t=z_t, use_pos_encoding_if_applicable=use_pos)                          # :181-185
         finally:
-            self.model._saved = None
+            net._saved = None
         lam = d.lambda_train[0]
         loss_X = loss_E = torch.zeros((1,))
         if loss_kind in ('ce', 'vbce'):
@@ -133,7 +134,8 @@ class TrainingMixin:
         z_t = z_t.get_new_object(X=z_t.X * free_x[:, :, None].float(), E=z_t.E * pair[..., None].float(), atom_map_numbers=am)  # :179
         return z_t, ~unconditional
 
-    def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None, pos_encodings=None):
+    def train_one_step(self, data: PlaceHolder, optimizer, i: int = 0, t_int=None, noise=None, z_t=None, group=None, pos_encodings=None,
+                       update_ema: bool = True):
         """training/helpers.py:130-142 for one batch: zero_grad, training_step, backward, gradient all-reduce over `group` (data
         parallel: one process per GPU, RCCL), fused AdamW step.  Returns the (detached) loss."""
         from . import distributed
@@ -144,6 +146,8 @@ class TrainingMixin:
         optimizer.gather()
         world = distributed.allreduce_flat_gradient(optimizer.flat_grad, group=group)
         optimizer.step(grad_scale=1.0 / world)
+        if update_ema and getattr(self, 'ema', None) is not None:     # (a captured step leaves it to its caller: the decay is host state)
+            self.ema.update()                                                                                 # training/helpers.py:143-144
         return loss.detach()
 
     def training_backward_output_stage(self) -> Dict[str, torch.Tensor]:
