@@ -43,7 +43,7 @@ SIGNATURES = {
     'da_pool_stats_fwd': 'i:ppppqiiip', 'da_linear_wgrad_workspace': 'q:qii', 'da_linear_wgrad': 'i:pppppqqiip',
     'da_pool_stats_bwd': 'i:pppppiiip',
     'da_vb_grad': 'i:ppppppppppppppffppiiiip',
-    'da_adamw': 'i:pppppqfffffifp', 'da_adamw_devstep': 'i:pppppqfffffpfp',
+    'da_adamw': 'i:pppppqfffffifpp', 'da_adamw_devstep': 'i:pppppqfffffpfpp',
     'da_edge_blob_bytes': 'q:iii',
     'da_edge_in_blob_bytes': 'q:ii',
     'da_edge_out_blob_bytes': 'q:ii',

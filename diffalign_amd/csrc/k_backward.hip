@@ -579,9 +579,10 @@ static void launch_wgrad(const float* X, const float* dY, float* dW, float* db, 
 // AdamW(amsgrad) on a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay, bias corrections by step).
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                float* __restrict__ vmax, long long N, float lr, float b1, float b2, float eps, float wd,
-                                               float bc1, float bc2_sqrt, float grad_scale) {
+                                               float bc1, float bc2_sqrt, float grad_scale, const uint8_t* __restrict__ slot_active) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
+  if (slot_active && !slot_active[t >> 6]) return;      // a parameter without a gradient this step: torch skips it (no decay, state frozen)
   const float gr = g[t] * grad_scale;
   float x = p[t];
   x *= 1.f - lr * wd;
@@ -597,9 +598,10 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const floa
 // computed on the device, so the launch carries no per-step host value and can be replayed from a HIP graph.  k_adamw_tick follows it.
 __global__ void __launch_bounds__(256) k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, long long N, float lr, float b1, float b2, float eps, float wd,
-                                                   const int* __restrict__ step, float grad_scale) {
+                                                   const int* __restrict__ step, float grad_scale, const uint8_t* __restrict__ slot_active) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N) return;
+  if (slot_active && !slot_active[t >> 6]) return;
   const float st = (float)(*step + 1);
   const float bc1 = 1.f - powf(b1, st), bc2_sqrt = sqrtf(1.f - powf(b2, st));
   const float gr = g[t] * grad_scale;
@@ -791,23 +793,24 @@ int da_vb_grad(const float* true_X, const float* true_E, const float* zt_X, cons
 }
 
 int da_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr, float beta1,
-             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+             float beta2, float eps, float weight_decay, int step, float grad_scale, const uint8_t* slot_active, void* stream) {
   DA_CHECK_ARG(N >= 0 && step >= 1 && param && grad && exp_avg && exp_avg_sq, "da_adamw: arguments");
   if (N == 0) return DA_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
   k_adamw<<<grid_for(N, 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, N, lr, beta1, beta2, eps, weight_decay,
-                                                          bc1, bc2, grad_scale);
+                                                          bc1, bc2, grad_scale, slot_active);
   DA_CHECK_LAUNCH("da_adamw");
   return DA_OK;
 }
 
 // da_adamw with the step counter in device memory (int, starts at 0, incremented here): for optimiser steps replayed from a HIP graph.
 int da_adamw_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, int* step_counter, float grad_scale, void* stream) {
+                     float beta1, float beta2, float eps, float weight_decay, int* step_counter, float grad_scale, const uint8_t* slot_active,
+                     void* stream) {
   DA_CHECK_ARG(N >= 0 && step_counter && param && grad && exp_avg && exp_avg_sq, "da_adamw_devstep: arguments");
   if (N > 0)
     k_adamw_dev<<<grid_for(N, 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, N, lr, beta1, beta2, eps,
-                                                                  weight_decay, step_counter, grad_scale);
+                                                                  weight_decay, step_counter, grad_scale, slot_active);
   k_adamw_tick<<<1, 1, 0, (hipStream_t)stream>>>(step_counter);
   DA_CHECK_LAUNCH("da_adamw_devstep");
   return DA_OK;

@@ -177,13 +177,16 @@ int da_vb_grad(const float* true_X, const float* true_E, const float* zt_X, cons
                const uint8_t* mask_e, const float* sums, float weight_X, float weight_E, float* grad_X, float* grad_E, int B, int n, int kx,
                int ke, void* stream);
 /* One AdamW step (torch.optim.AdamW semantics, decoupled weight decay; amsgrad when max_exp_avg_sq != NULL: utils/setup.py:356) on
- * a flat buffer of N parameters; grad is multiplied by grad_scale first (1 / world size, or the inverse loss scale). */
+ * a flat buffer of N parameters; grad is multiplied by grad_scale first (1 / world size, or the inverse loss scale).
+ * slot_active (ceil(N / 64) bytes, or NULL = all): 64-element slots whose byte is 0 are left untouched -- parameters without a
+ * gradient in this step, which torch.optim skips (no decay, moments frozen). */
 int da_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr, float beta1,
-             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+             float beta2, float eps, float weight_decay, int step, float grad_scale, const uint8_t* slot_active, void* stream);
 /* da_adamw with the number of updates done so far in device memory (*step_counter, int, starts at 0; incremented by the call): no
  * per-step host value in the launch, so a whole training step can be replayed from a HIP graph. */
 int da_adamw_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long N, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, int* step_counter, float grad_scale, void* stream);
+                     float beta1, float beta2, float eps, float weight_decay, int* step_counter, float grad_scale, const uint8_t* slot_active,
+                     void* stream);
 
 /* ---- L2 denoiser (graph transformer) -------------------------------------------------------------------------------
  * Hidden edge features travel between these calls as bf16 (B,n,n,de); node features X and globals y stay fp32.

@@ -291,6 +291,58 @@ def test_fused_adamw_matches_torch():
     assert all(m.data_ptr() >= o.flat_param.data_ptr() for m in mine)                 # parameters live in the flat buffer
 
 
+@pytest.mark.parametrize('device_step', [False, True])
+def test_adamw_checkpoint_exchange_with_torch_and_scheduler(device_step):
+    """optimizer_state_dict in torch.optim.AdamW's format, both ways (training/helpers.py:99-110, utils/setup.py:331-346), with a
+    parameter that never receives a gradient (torch keeps no state for it), and a torch learning-rate scheduler driving the step size."""
+    from diffalign_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 5), (13,), (2, 2), (3, 4, 2)]
+    dead = 2                                                                            # index of the parameter without a gradient
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=True)
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(9)]
+
+    def run(opt, params, lo, hi, sched=None):
+        for t in range(lo, hi):
+            opt.zero_grad()
+            for i, p in enumerate(params):
+                if i != dead:
+                    p.grad = grads[t][i].to(p.device).clone()
+            if isinstance(opt, FlatAdamW):
+                opt.gather()
+            opt.step()
+            if sched is not None:
+                sched.step()
+
+    mk_sched = lambda o: torch.optim.lr_scheduler.StepLR(o, step_size=2, gamma=0.5)
+    # torch for 3 steps -> checkpoint -> this optimiser for 3 steps -> checkpoint -> torch for 3 steps; reference: torch for 9 steps
+    ref = [p.clone().requires_grad_() for p in ps]
+    o_ref = torch.optim.AdamW(ref, **kw); s_ref = mk_sched(o_ref)
+    run(o_ref, ref, 0, 9, s_ref)
+    a = [p.clone().requires_grad_() for p in ps]
+    o_a = torch.optim.AdamW(a, **kw); s_a = mk_sched(o_a)
+    run(o_a, a, 0, 3, s_a)
+    ck1 = dict(opt=o_a.state_dict(), sched=s_a.state_dict())
+    assert dead not in ck1['opt']['state']
+    b = [torch.nn.Parameter(p.detach().clone().to(D)) for p in a]
+    o_b = FlatAdamW(b, device_step=device_step, **kw); s_b = mk_sched(o_b)
+    o_b.load_state_dict(ck1['opt']); s_b.load_state_dict(ck1['sched'])
+    assert o_b.steps == 3 and abs(o_b.lr - o_a.param_groups[0]['lr']) < 1e-12
+    run(o_b, b, 3, 6, s_b)
+    ck2 = dict(opt=o_b.state_dict(), sched=s_b.state_dict())
+    assert sorted(ck2['opt']['state']) == sorted(ck1['opt']['state']) and float(ck2['opt']['state'][0]['step']) == 6.0
+    c = [p.detach().cpu().clone().requires_grad_() for p in b]
+    o_c = torch.optim.AdamW(c, **kw); s_c = mk_sched(o_c)
+    o_c.load_state_dict({'state': {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in ck2['opt']['state'].items()},
+                         'param_groups': ck2['opt']['param_groups']})
+    s_c.load_state_dict(ck2['sched'])
+    run(o_c, c, 6, 9, s_c)
+    for r, m in zip(ref, c):
+        assert (m.detach() - r.detach()).abs().max() <= 2e-6
+    assert torch.equal(c[dead].detach(), ps[dead])
+
+
 def test_optimisation_steps_reduce_the_loss_and_refresh_the_inference_weights():
     """train_one_step x 8 on one fixed batch (ce): the loss falls; with dropout > 0 the step stays finite; the fused bf16
     inference path re-packs the updated weights (its loss follows the trained fp32 one)."""

@@ -78,3 +78,40 @@ def test_graphed_training_step_updates_ema_outside_the_graph():
     online, avg = dict(model.model.named_parameters()), dict(model.ema.ema_model.named_parameters())
     d = (avg['mlp_in_X.0.weight'] - online['mlp_in_X.0.weight'].detach()).abs().max()
     assert 0 < float(d) < 0.1
+
+
+def test_checkpoint_resume_reproduces_the_run(tmp_path):
+    """training/helpers.py:99-110 + utils/setup.py:331-346: save after 3 steps, load into fresh objects, 3 more steps on both: same
+    weights, optimiser state, learning rate and EMA (the backward's float atomics leave 1e-6 of run-to-run difference)."""
+    from diffalign_amd.optim import FlatAdamW
+    from diffalign_amd import checkpoint as CK
+    z, model, data = ema_model()
+    t = T(z['train_t']).float().to(D)
+    model.train()
+    opt = FlatAdamW(model.model.parameters(), lr=2e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+
+    def run(m, o, s, k):
+        for _ in range(k):
+            m.train_one_step(data, o, t_int=t, z_t=None, noise=None)
+            s.step()
+
+    torch.manual_seed(1)
+    run(model, opt, sched, 3)
+    path = str(tmp_path / 'epoch3.pt')
+    CK.save_checkpoint(path, model, opt, sched)
+    ck = torch.load(path, map_location='cpu', weights_only=True)
+    assert {'model_state_dict', 'optimizer_state_dict', 'scheduler_state_dict', 'scaler_state_dict', 'rng_state', 'ema_state_dict'} <= set(ck)
+    assert any(k.startswith('model.tf_layers.0.') for k in ck['model_state_dict']) and 'initted' in ck['ema_state_dict']
+    _, model2, _ = ema_model()
+    model2.train()
+    opt2 = FlatAdamW(model2.model.parameters(), lr=2e-3)
+    sched2 = torch.optim.lr_scheduler.StepLR(opt2, step_size=2, gamma=0.5)
+    CK.load_all_state_dicts(model2.cfg, model2, opt2, sched2, None, path)
+    assert opt2.steps == 3 and opt2.lr == opt.lr and model2.ema._host_step == 3
+    # the same random draws (t is fixed; the noise of apply_noise comes from torch's generator) on both continuations
+    torch.manual_seed(2); run(model, opt, sched, 3)
+    torch.manual_seed(2); run(model2, opt2, sched2, 3)
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=0, atol=5e-6), k
+    assert torch.allclose(opt.exp_avg, opt2.exp_avg, atol=1e-6) and torch.allclose(opt.max_exp_avg_sq, opt2.max_exp_avg_sq, atol=1e-6)
