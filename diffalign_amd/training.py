@@ -178,3 +178,25 @@ class TrainingMixin:
             tot = part.double().sum(0).float()
             out['skip_scaling'], out['skip_scaling_2'] = tot[0:1], tot[1:2]
         return out
+
+
+def train_one_epoch(model, batches, optimizer, scheduler=None, *, epoch: int = 0, losses: Optional[list] = None, group=None, shuffle: bool = True):
+    """training/helpers.py:121-152: one pass over `batches` (dense PlaceHolders on the device, or sparse batches graph.to_dense accepts;
+    the reference's size-binned batches have different (B, n) and are taken as they come), `scheduler.step()` once per epoch, the
+    epoch's average loss appended to `losses` and returned.  The running sum stays on the device: one host sync per epoch, where the
+    reference syncs on every batch (`loss.cpu()`, :137)."""
+    import random
+    model.train()
+    if shuffle:
+        random.shuffle(batches)                                                                              # :127
+    total = None
+    for i, batch in enumerate(batches):
+        dense = batch if isinstance(batch, PlaceHolder) else graph.to_dense(batch)
+        loss = model.train_one_step(dense, optimizer, i, group=group)                                        # :132-144
+        total = loss.clone() if total is None else total + loss
+    if scheduler is not None:
+        scheduler.step()                                                                                     # :146
+    avg = float(total) / max(len(batches), 1) if total is not None else 0.0
+    if losses is not None:
+        losses.append(avg)
+    return avg

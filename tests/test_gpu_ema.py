@@ -115,3 +115,28 @@ def test_checkpoint_resume_reproduces_the_run(tmp_path):
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert torch.allclose(a.float(), b.float(), rtol=0, atol=5e-6), k
     assert torch.allclose(opt.exp_avg, opt2.exp_avg, atol=1e-6) and torch.allclose(opt.max_exp_avg_sq, opt2.max_exp_avg_sq, atol=1e-6)
+
+
+def test_train_one_epoch_over_size_binned_batches():
+    """training/helpers.py:121-152 on three batches of different (B, n) (the reference bins graphs by size), two epochs."""
+    from diffalign_amd.optim import FlatAdamW
+    from diffalign_amd.training import train_one_epoch
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    z, model, _ = ema_model()
+    model.pos_encodings_fn = None
+    model.cfg.neuralnet.pos_encoding_type = 'smiles_pos_enc'
+
+    def batch(B, n, seed):
+        d = S.make_reaction_batch(B, n, seed=seed)
+        return PlaceHolder(X=d['X'].to(D), E=d['E'].to(D), y=torch.zeros(B, 1, device=D), node_mask=d['node_mask'].to(D),
+                           atom_map_numbers=d['atom_map_numbers'].to(D), mol_assignments=d['mol_assignments'].to(D))
+    batches = [batch(4, 24, 1), batch(3, 40, 2), batch(2, 33, 3)]
+    opt = FlatAdamW(model.model.parameters(), lr=2e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    losses = []
+    torch.manual_seed(0)
+    for epoch in range(4):
+        train_one_epoch(model, batches, opt, sched, epoch=epoch, losses=losses)
+    assert len(losses) == 4 and all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0], losses
+    assert abs(opt.lr - 2e-3 * 0.5 ** 4) < 1e-12 and opt.steps == 12 and int(model.ema.step) == 12
