@@ -162,8 +162,11 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         """diffusion_abstract.py:293-348 (denoiser='neuralnet').  The reference's random relabelling of atom-map
         numbers (:297-300) is output-invariant and is skipped (it only consumes RNG and a host sync).
         `step`: helpers.reverse_step_ctx(...) -- the reverse step fused behind the output stage (see reverse_step)."""
+        if self.cfg.diffusion.denoiser == 'random-uniform':                # :312-317: equal node logits, E as it came in
+            return z_t.get_new_object(X=torch.ones_like(z_t.X))
         if self.cfg.diffusion.denoiser != 'neuralnet':
-            raise NotImplementedError("only denoiser='neuralnet' is built")
+            # 'carbon' (:304-311) reads mol.atom_types / mol.atom_type_offset, which utils/mol.py does not define: it cannot run there either
+            raise NotImplementedError(f"denoiser={self.cfg.diffusion.denoiser!r}: 'neuralnet' and 'random-uniform' are built")
         z_in = self.compute_extra_data(z_t) if self.cfg.neuralnet.extra_features else z_t
         if self.cfg.neuralnet.architecture == 'with_y_atommap_number_pos_enc':
             assert z_t.mol_assignments is not None, 'molecule_assigments is None in forward()'

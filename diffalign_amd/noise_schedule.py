@@ -20,15 +20,52 @@ def cosine_beta_schedule_discrete(timesteps: int, s: float = 0.008) -> np.ndarra
     return (1 - ac[1:] / ac[:-1]).squeeze()
 
 
+def _cosine_cumprod(timesteps: int, s: float) -> np.ndarray:
+    steps = timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(0.5 * np.pi * ((x / steps) + s) / (1 + s)) ** 2
+    return ac / ac[0]
+
+
+def cosine_beta_schedule_discrete_alternate(timesteps: int) -> np.ndarray:
+    """utils/diffusion/helpers.py:645-656: betas = 1 - the cumulative product itself (zero transition probability at t = 0; the
+    reference notes that the overall shape differs from the cosine schedule)."""
+    return (1 - _cosine_cumprod(timesteps, 0.0)).squeeze()
+
+
+def cosine_beta_schedule_discrete_alternate_2(timesteps: int) -> np.ndarray:
+    """utils/diffusion/helpers.py:658-670: the s = 0 cosine ratios behind a leading alpha of 1."""
+    ac = _cosine_cumprod(timesteps, 0.0)
+    return (1 - np.concatenate([np.array([1.0]), ac[1:] / ac[:-1]])).squeeze()
+
+
+def custom_beta_schedule_discrete(timesteps: int, average_num_nodes: int = 50, s: float = 0.008) -> np.ndarray:
+    """utils/diffusion/helpers.py:672-692: cosine betas floored at 1.2 expected edge updates per graph and step."""
+    assert timesteps >= 100
+    betas = cosine_beta_schedule_discrete(timesteps, s).copy()
+    num_edges = average_num_nodes * (average_num_nodes - 1) / 2
+    beta_first = 1.2 / ((4 / 5) * num_edges)
+    betas[betas < beta_first] = beta_first
+    return np.array(betas)
+
+
 class PredefinedNoiseScheduleDiscrete(torch.nn.Module):
-    """noise_schedule.py:43-86 ('cosine' only: the other schedules are not on the align_* path)."""
+    """noise_schedule.py:43-86."""
 
     def __init__(self, noise_schedule: str, timesteps: int):
         super().__init__()
-        if noise_schedule != 'cosine':
-            raise NotImplementedError(noise_schedule)
         self.timesteps = timesteps
-        betas = torch.from_numpy(cosine_beta_schedule_discrete(timesteps, s=0)).float()
+        if noise_schedule == 'cosine':
+            b = cosine_beta_schedule_discrete(timesteps, s=0)
+        elif noise_schedule == 'cosine_alternate':
+            b = cosine_beta_schedule_discrete_alternate(timesteps)
+        elif noise_schedule == 'cosine_alternate_2':
+            b = cosine_beta_schedule_discrete_alternate_2(timesteps)
+        elif noise_schedule == 'custom':
+            b = custom_beta_schedule_discrete(timesteps)
+        else:
+            raise NotImplementedError(noise_schedule)
+        betas = torch.from_numpy(b).float()
         self.register_buffer('betas', betas)
         self.alphas = 1 - torch.clamp(self.betas, min=0, max=0.9999)
         self.alphas_bar = torch.exp(torch.cumsum(torch.log(self.alphas), dim=0))
