@@ -80,9 +80,25 @@ class PositionalEmbedding(nn.Module):
 
     def matched_positional_encodings_infoleak(self, atom_map_numbers, molecule_assignments, direction='retro'):
         """:451-490 with pos_emb_permutations = 0: sinusoidal embedding of the atom-map number itself."""
-        if self.pos_emb_permutations != 0:
-            raise NotImplementedError('pos_emb_permutations != 0 (random relabelling of atom-map numbers, :458-485) is not built')
         B, n = atom_map_numbers.shape
+        if self.pos_emb_permutations != 0:
+            # :458-485: every graph's numbers 1..max are relabelled by one of `pos_emb_permutations` fixed shuffles (or, for -1, a fresh
+            # one).  The shuffles come from Python's / numpy's host generators exactly as in the reference (same calls, same order), so
+            # a seeded run relabels alike; the table goes to the device once and the relabelling is one gather.
+            import random
+            import numpy as np
+            max_am = atom_map_numbers.max(-1).values.cpu().int()
+            perms = [list(range(1, int(m) + 1)) for m in max_am]
+            if self.pos_emb_permutations > 0:
+                perm_numbers = np.random.randint(0, self.pos_emb_permutations, B)
+                for idx, pn in enumerate(perm_numbers):
+                    random.Random(pn).shuffle(perms[idx])
+            else:
+                for idx in range(B):
+                    random.shuffle(perms[idx])
+            width = int(max(max_am))
+            table = torch.tensor([[0] + p + (width - len(p)) * [0] for p in perms], device=atom_map_numbers.device)
+            atom_map_numbers = table.gather(1, atom_map_numbers.long())
         return self.pos_emb(atom_map_numbers.float()).reshape(B, n, self.dim)
 
     def matched_positional_encodings_gaussian(self, atom_map_numbers, molecule_assignments, noise: Optional[torch.Tensor] = None):

@@ -51,6 +51,21 @@ def test_laplacian_encodings_vs_reference_golden(tag, variant):
     assert done == total and total >= 15, (done, total)
 
 
+@pytest.mark.parametrize('perms', [3, -1])
+def test_infoleak_with_permuted_atom_map_numbers(perms):
+    """:458-485: the relabelling uses the host generators as the reference does; seeded alike it gives the reference's encodings."""
+    import random
+    import numpy as np
+    from diffalign_amd.pos_encodings import PositionalEmbedding
+    z = load('pos_perm')
+    am, mol = torch.from_numpy(z['am']).to(D), torch.from_numpy(z['mol']).to(D)
+    np.random.seed(7); random.seed(7)
+    out = PositionalEmbedding(int(z['dim']), perms).matched_positional_encodings_infoleak(am, mol)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(z[f'perm{perms}']), atol=2e-6, rtol=0)
+    plain = PositionalEmbedding(int(z['dim']), 0).matched_positional_encodings_infoleak(am, mol)
+    assert not torch.equal(out, plain) and torch.equal(out[am == 0], plain[am == 0])
+
+
 def test_laplacian_encodings_properties():
     from diffalign_amd.pos_encodings import PositionalEmbedding
     from diffalign_amd import synthetic as S
