@@ -350,11 +350,12 @@ def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n,
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
-                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None, edge_skip_uniform=False):
+                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None, edge_skip_uniform=False, align_src=None):
     """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
     `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py).
     `step`: the reverse step fused behind the output stage (helpers.ReverseStep.ctx: z_t, transition tables, noise, masks): the edge
     half is drawn inside the output kernel (da_edge_out_sample) and the edge logits are not materialised (Eo is None); the node half runs behind the node output path.  The drawn state lands in step['zs_X'], step['zs_E'].
+    `align_src` (B,n) int32: the skip connection's product index per node when it is not da_align_index's (alignment_type='old').
     `edge_skip_uniform`: input_alignment=True scales the whole edge skip term by skip_scaling_2 (transformer_model_with_y.py:702-704)."""
     dev = X.device
     B, n = X.shape[:2]
@@ -374,14 +375,14 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     src = None
     if use_skip:
         assert pm.skip is not None and atom_map_numbers is not None and mol_assignments is not None
-        src = torch.empty(B, n, dtype=torch.int32, device=dev)
+        src = align_src.contiguous() if align_src is not None else torch.empty(B, n, dtype=torch.int32, device=dev)
         am64, mol64 = atom_map_numbers.contiguous(), mol_assignments.contiguous()
 
     def node_input_path():
         _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
         _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
         L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), L.stream()), 'da_x_in_finish')
-        if use_skip:
+        if use_skip and align_src is None:
             L.check(lib.da_align_index(L.ptr(am64, torch.int64), L.ptr(mol64, torch.int64), L.ptr(src), _i(B), _i(n), L.stream()),
                     'da_align_index')
 

@@ -43,14 +43,37 @@ def _layer(layer, X, E, y, nm_u8, xm, em, training):
     return X, E, y
 
 
-def aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke):
+def align_index(atom_map_numbers, mol_assignments, alignment_type='correct'):
+    """src (B,n) int32: for every reactant-side node with an atom-map number its product node, else -1.
+    'correct' (transformer_model_with_y.py:540-552): the product node carrying the same number (da_align_index).
+    'old' (:526-538): create_permutation_matrix_torch on the two index lists minus their minima -- both increasing, so the matrix is
+    the identity: the k-th mapped reactant-side node (in node order) takes the k-th mapped product node, whatever their numbers."""
+    B, n = atom_map_numbers.shape
+    dev = atom_map_numbers.device
+    if alignment_type == 'correct':
+        src = torch.empty(B, n, dtype=torch.int32, device=dev)
+        L.check(L.lib().da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
+                                       L.ptr(src), B, n, L.stream()), 'da_align_index')
+        return src
+    if alignment_type != 'old':
+        raise ValueError(f'Alignment type not set correctly ({alignment_type}). Should be old or correct')
+    is_prod = mol_assignments == mol_assignments.max(-1, keepdim=True).values
+    mapped = atom_map_numbers > 0
+    rct, prod = mapped & ~is_prod, mapped & is_prod
+    ar = torch.arange(n, device=dev).expand(B, n)
+    # node indices of the mapped product nodes in increasing order, padded with n
+    prod_sorted = torch.where(prod, ar, torch.full_like(ar, n)).sort(-1).values
+    rank = rct.long().cumsum(-1) - 1
+    src = torch.where(rct, prod_sorted.gather(1, rank.clamp_min(0)), torch.full_like(ar, -1))
+    return torch.where(src == n, torch.full_like(src, -1), src).int()          # (the reference asserts equal counts, :523)
+
+
+def aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke, alignment_type='correct'):
     """transformer_model_with_y.py:506-555 (alignment 'correct') + :633-645 as gathers: for every reactant-side node r with an atom-map
     number, the input features of the product node p(r) carrying the same number.  Returns (X_al (B,n,kx): X[p(r), :kx] on mapped
     rows, else 0;  E_al (B,n,n,ke): E[p(r1), p(r2), :ke] on mapped pairs, else one-hot class 0;  pair (B,n,n,1) bool)."""
     B, n = X.shape[:2]
-    src = torch.empty(B, n, dtype=torch.int32, device=X.device)
-    L.check(L.lib().da_align_index(L.ptr(atom_map_numbers.contiguous(), torch.int64), L.ptr(mol_assignments.contiguous(), torch.int64),
-                                   L.ptr(src), B, n, L.stream()), 'da_align_index')
+    src = align_index(atom_map_numbers, mol_assignments, alignment_type)
     sel = src >= 0
     idx = src.clamp_min(0).long()
     X_al = torch.gather(X[..., :kx], 1, idx[:, :, None].expand(-1, -1, kx)) * sel[:, :, None]
@@ -69,7 +92,7 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
     B, n = X.shape[:2]
     X_al = E_al = None
     if getattr(m, 'input_alignment', False):                             # :630-647: the aligned product features as extra input channels
-        X_al, E_al, _ = aligned_product_features(X, E, atom_map_numbers, mol_assignments, m.out_dim_X, m.out_dim_E)
+        X_al, E_al, _ = aligned_product_features(X, E, atom_map_numbers, mol_assignments, m.out_dim_X, m.out_dim_E, m.alignment_type)
         X, E = torch.cat([X, X_al], -1), torch.cat([E, E_al], -1)
     nm_u8 = L.as_u8(node_mask)
     xm = node_mask[:, :, None].float()
@@ -92,7 +115,7 @@ def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=No
         # every other pair s2 on class 0; with input_alignment the reference reuses the concatenated tensors and scales ALL of the edge
         # part by s2 (:702-704)
         if X_al is None:
-            X_al, E_al, pair = aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke)
+            X_al, E_al, pair = aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke, m.alignment_type)
             Eo = Eo + torch.where(pair, m.skip_scaling * E_al, m.skip_scaling_2 * E_al)
         else:
             Eo = Eo + m.skip_scaling_2 * E_al

@@ -83,8 +83,8 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
             input_dims = dict(input_dims)
             input_dims['X'] += output_dims['X']
             input_dims['E'] += output_dims['E']
-        if (p_to_r_skip_connection or input_alignment) and alignment_type != 'correct':
-            raise NotImplementedError("alignment_type='old' is not built (align_absorbing uses 'correct')")
+        if (p_to_r_skip_connection or input_alignment) and alignment_type not in ('old', 'correct'):
+            raise ValueError(f'Alignment type not set correctly ({alignment_type}). Should be old or correct')       # :554
         self.pos_emb_permutations = pos_emb_permutations
         self.p_to_r_skip_connection = p_to_r_skip_connection
         self.alignment_type = alignment_type
@@ -104,10 +104,15 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
         pm = self._pack(X.device)
         if self.input_alignment:                                         # :630-647
             from .train_forward import aligned_product_features
-            X_al, E_al, _ = aligned_product_features(X.float(), E.float(), atom_map_numbers, mol_assignments, self.out_dim_X, self.out_dim_E)
+            X_al, E_al, _ = aligned_product_features(X.float(), E.float(), atom_map_numbers, mol_assignments, self.out_dim_X, self.out_dim_E,
+                                                     self.alignment_type)
             X, E = torch.cat([X.float(), X_al], -1), torch.cat([E.float(), E_al], -1)
+        src = None
+        if self.p_to_r_skip_connection and self.alignment_type == 'old':     # rank alignment (:526-538) instead of da_align_index
+            from .train_forward import align_index
+            src = align_index(atom_map_numbers, mol_assignments, 'old')
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
                                           use_skip=self.p_to_r_skip_connection, save=self._saved, step=step,
-                                          edge_skip_uniform=self.input_alignment)
+                                          edge_skip_uniform=self.input_alignment, align_src=src)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask

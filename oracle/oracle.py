@@ -377,6 +377,22 @@ def align_index(atom_map_numbers: Tensor, mol_assignments: Tensor) -> Tensor:
     return src
 
 
+def align_index_old(atom_map_numbers: Tensor, mol_assignments: Tensor) -> Tensor:
+    """alignment_type='old' (transformer_model_with_y.py:526-538): create_permutation_matrix_torch (utils/math_utils.py:3-44) matches
+    the two lists rank by rank, and both lists (node indices minus their minimum) are increasing, so the k-th atom-mapped
+    reactant-side node takes the k-th atom-mapped product node."""
+    B, n = atom_map_numbers.shape
+    is_prod = mol_assignments == mol_assignments.max(-1).values[:, None]
+    src = torch.full((B, n), -1, dtype=torch.long)
+    for b in range(B):
+        prod = [i for i in range(n) if is_prod[b, i] and atom_map_numbers[b, i] > 0]
+        rct = [i for i in range(n) if not is_prod[b, i] and atom_map_numbers[b, i] > 0]
+        assert len(prod) == len(rct)
+        for r, p in zip(rct, prod):
+            src[b, r] = p
+    return src
+
+
 def p_to_r_skip(X_o, E_o, X_in, E_in, src: Tensor, s1, s2, Kx: int, Ke: int):
     """transformer_model_with_y.py:686-701.  s1, s2: floats or the (1,) parameters themselves (then differentiable in them)."""
     X_o = X_o.clone(); E_o = E_o.clone()
@@ -410,13 +426,14 @@ def aligned_inputs(X_in, E_in, src: Tensor, Kx: int, Ke: int):
 
 def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n_head: int,
                      out_dims: Tuple[int, int, int], atom_map_numbers=None, pos_encodings=None,
-                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = '', input_alignment=False):
+                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = '', input_alignment=False, alignment_type='correct'):
     """transformer_model_with_y.py:620-713 (atom-map variant when pos_encodings is given) and
     :74-111 (plain GraphTransformerWithY).  Returns un-masked logits (X, E, y)."""
     Kx, Ke, Ky = out_dims
     B, n = X.shape[:2]
+    align = align_index if alignment_type == 'correct' else align_index_old
     if input_alignment:
-        Xc, Ec = aligned_inputs(X, E, align_index(atom_map_numbers, mol_assignments), Kx, Ke)
+        Xc, Ec = aligned_inputs(X, E, align(atom_map_numbers, mol_assignments), Kx, Ke)
         X, E = torch.cat([X, Xc], -1), torch.cat([E, Ec], -1)
     X_in, E_in = X, E
     def mlp_in(name, t):
@@ -438,7 +455,7 @@ def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n
         Xo = Xo + Xc * sd[prefix + 'skip_scaling']
         Eo = Eo + Ec * sd[prefix + 'skip_scaling_2']
     elif p_to_r_skip_connection:
-        src = align_index(atom_map_numbers, mol_assignments)
+        src = align(atom_map_numbers, mol_assignments)
         Xo, Eo = p_to_r_skip(Xo, Eo, X_in, E_in, src, sd[prefix + 'skip_scaling'], sd[prefix + 'skip_scaling_2'], Kx, Ke)
     return Xo, Eo, yo
 

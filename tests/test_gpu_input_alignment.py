@@ -16,11 +16,11 @@ from tests.test_oracle_golden import inalign_weights
 pytestmark = pytest.mark.gpu
 
 
-def build(dims, n_layers, skip, sd=None, seed=45):
+def build(dims, n_layers, skip, sd=None, seed=45, align='correct', inal=True):
     from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
     m = GraphTransformerWithYAtomMapPosEmb(n_layers, IN_DIMS, dims['hidden_mlp_dims'], dims['hidden_dims'], OUT_DIMS, nn.ReLU(), nn.ReLU(),
-                                           dropout=0.0, p_to_r_skip_connection=skip, p_to_r_init=1.0, alignment_type='correct',
-                                           input_alignment=True).eval()
+                                           dropout=0.0, p_to_r_skip_connection=skip, p_to_r_init=1.0, alignment_type=align,
+                                           input_alignment=inal).eval()
     if sd is None:
         sd = init_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
         if skip:
@@ -90,3 +90,32 @@ def test_training_forward_and_gradients_vs_oracle(skip):
             continue
         err = float((p.grad.cpu() - want).norm()) / (float(want.norm()) + 1e-6)
         assert err <= 1e-4, (name, err)
+
+
+@pytest.mark.parametrize('inal', [False, True])
+def test_alignment_type_old_vs_reference_golden_and_training(inal):
+    """alignment_type='old' (:526-538, rank alignment): inference against the reference's logits, the training forward and its
+    gradients against the oracle."""
+    from tests.test_oracle_golden import plain_weights_seed45
+    z = load('model_inalign')
+    sd = inalign_weights(z) if inal else plain_weights_seed45()
+    m, _ = build(TINY, int(z['n_layers']), True, sd=sd, align='old', inal=inal)
+    X = torch.cat([F.one_hot(T(z['X_idx']), KX).float(), T(z['X_extra'])], -1)
+    E = F.one_hot(T(z['E_idx']), KE).float()
+    args = (T(z['y_in']), T(z['node_mask']), T(z['am']), T(z['pos']), T(z['mol']))
+    with torch.no_grad():
+        r = m(X.to(D), E.to(D), *[a.to(D) for a in args])
+    tag = 'old_inal_skip' if inal else 'old_skip'
+    for a_, name in ((r[0], 'X'), (r[1], 'E')):
+        assert rel_l2(a_, T(z[f'{tag}_{name}'])) <= 2e-2, (name, rel_l2(a_, T(z[f'{tag}_{name}'])))
+    m.train()
+    rt = m(X.to(D), E.to(D), *[a.to(D) for a in args])
+    assert (rt[0].detach().cpu() - T(z[f'{tag}_X'])).abs().max() <= 2e-4 and (rt[1].detach().cpu() - T(z[f'{tag}_E'])).abs().max() <= 2e-4
+    osd = {k: v.clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    o = O.denoiser_forward(osd, X, E, args[0], args[1], int(z['n_layers']), int(z['n_head']), (KX, KE, 1), args[2], args[3], args[4], True,
+                           input_alignment=inal, alignment_type='old')
+    (o[0].sum() + (o[1] ** 2).sum()).backward()
+    (rt[0].sum() + (rt[1] ** 2).sum()).backward()
+    for name in ('skip_scaling', 'skip_scaling_2', 'mlp_in_E.0.weight', 'mlp_out_E.2.weight'):
+        want, got = osd[name].grad, dict(m.named_parameters())[name].grad.cpu()
+        assert float((got - want).norm()) <= 1e-4 * float(want.norm()) + 1e-6, name

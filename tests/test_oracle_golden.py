@@ -133,6 +133,31 @@ def test_model_input_alignment():
         close(r[0], z[f'{tag}_X'], 5e-5); close(r[1], z[f'{tag}_E'], 5e-5); close(r[2], z[f'{tag}_y'], 5e-5)
 
 
+def plain_weights_seed45():
+    """Weights of the 'old_skip' case of model_inalign.npz (no input alignment): the seeded initialiser on the module's own shapes."""
+    import torch.nn as nn
+    from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
+    from tests.golden.common import init_state_dict, tiny_dims
+    d = tiny_dims()
+    m = GraphTransformerWithYAtomMapPosEmb(d['n_layers'], {'X': KX + 8, 'E': KE, 'y': 13}, d['hidden_mlp_dims'], d['hidden_dims'],
+                                           {'X': KX, 'E': KE, 'y': 1}, nn.ReLU(), nn.ReLU(), p_to_r_skip_connection=True, alignment_type='old')
+    sd = init_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=45)
+    sd['skip_scaling'] = torch.tensor([0.7]); sd['skip_scaling_2'] = torch.tensor([1.3])
+    return sd
+
+
+def test_model_alignment_type_old():
+    """alignment_type='old' (:526-538): rank alignment, with the skip connection alone and with input_alignment."""
+    z = load('model_inalign')
+    X, E, y, nm, am, pos, mol = _model_inputs(z)
+    L, H = int(z['n_layers']), int(z['n_head'])
+    assert not torch.equal(O.align_index(am, mol), O.align_index_old(am, mol))      # the fixture tells the two alignments apart
+    r = O.denoiser_forward(plain_weights_seed45(), X, E, y, nm, L, H, (KX, KE, 1), am, pos, mol, True, alignment_type='old')
+    close(r[0], z['old_skip_X'], 5e-5); close(r[1], z['old_skip_E'], 5e-5)
+    r = O.denoiser_forward(inalign_weights(z), X, E, y, nm, L, H, (KX, KE, 1), am, pos, mol, True, input_alignment=True, alignment_type='old')
+    close(r[0], z['old_inal_skip_X'], 5e-5); close(r[1], z['old_inal_skip_E'], 5e-5)
+
+
 def test_model_full_dims_one_layer():
     from tests.golden.common import init_state_dict
     import ast
