@@ -25,9 +25,12 @@ class Etoy(nn.Module):
 
 
 class NodeEdgeBlock(nn.Module):
-    """layers.py:166-202 (parameters); forward is fused into XEyTransformerLayer's HIP path."""
-    def __init__(self, dx, de, dy, n_head, **kwargs):
+    """layers.py:166-202 (parameters); forward is fused into XEyTransformerLayer's HIP path.
+    `improved`: the parameters of NodeEdgeBlockImproved (layers.py:49-85) are the same set under the same names (its y_e_mul /
+    y_e_add exist but are unused); only the arithmetic differs (train_forward._node_edge_block_improved)."""
+    def __init__(self, dx, de, dy, n_head, improved=False, **kwargs):
         super().__init__()
+        self.improved = improved
         assert dx % n_head == 0, f"dx: {dx} -- nhead: {n_head}"
         self.dx, self.de, self.dy, self.df, self.n_head = dx, de, dy, dx // n_head, n_head
         self.q = Linear(dx, dx); self.k = Linear(dx, dx); self.v = Linear(dx, dx)
@@ -45,11 +48,9 @@ class XEyTransformerLayer(nn.Module):
     def __init__(self, dx: int, de: int, dy: int, n_head: int, dim_ffX: int = 2048, dim_ffE: int = 128, dim_ffy: int = 2048,
                  dropout: float = 0.1, layer_norm_eps: float = 1e-5, device=None, dtype=None, improved=False) -> None:
         super().__init__()
-        if improved:
-            raise NotImplementedError('NodeEdgeBlockImproved (cfg.neuralnet.improved=True) is not on the align_* path')
         assert layer_norm_eps == 1e-5
         kw = {'device': device, 'dtype': dtype}
-        self.self_attn = NodeEdgeBlock(dx, de, dy, n_head)
+        self.self_attn = NodeEdgeBlock(dx, de, dy, n_head, improved=improved)                       # layers.py:302
         self.linX1 = Linear(dx, dim_ffX, **kw); self.linX2 = Linear(dim_ffX, dx, **kw)
         self.normX1 = LayerNorm(dx, eps=layer_norm_eps, **kw); self.normX2 = LayerNorm(dx, eps=layer_norm_eps, **kw)
         self.linE1 = Linear(de, dim_ffE, **kw); self.linE2 = Linear(dim_ffE, de, **kw)

@@ -30,10 +30,28 @@ def _node_edge_block(a, X, E, y, nm_u8, xm, em):
     return newX, newE, new_y
 
 
+def _node_edge_block_improved(a, X, E, y, nm_u8, xm, em):
+    """layers.py:87-164 NodeEdgeBlockImproved: the edge update takes Y without the y FiLM, and attention is ONE softmax per head over the
+    head's summed scores (the plain block has one per channel).  Off in both align_* experiments (configs/neuralnet/transformer.yaml:15);
+    written in torch ops over the library GEMMs -- it has no fused HIP form, inference runs this same code without a graph."""
+    B, n, dx = X.shape
+    H, df = a.n_head, a.df
+    Q, K, V = a.q(X) * xm, a.k(X) * xm, a.v(X) * xm
+    Y = Q[:, :, None, :] * K[:, None, :, :] * qscale_of(a.dx, a.n_head)                        # (B,i,j,dx)
+    Y = Y * (wide_linear(a.e_mul, E) * em + 1) + wide_linear(a.e_add, E) * em                 # :115-122
+    newE = wide_linear(a.e_out, Y) * em                                                       # :123-125
+    attn = torch.softmax(Y.reshape(B, n, n, H, df).sum(-1), dim=2)                            # :128-130 (over keys, no mask)
+    wV = torch.einsum('bijh,bjhf->bihf', attn, V.reshape(B, n, H, df)).reshape(B, n, dx)      # :132-141
+    newX = a.x_out(a.y_x_add(y)[:, None, :] + (a.y_x_mul(y)[:, None, :] + 1) * wV) * xm       # :148-153
+    new_y = a.y_out(y + a.x_y.lin(PoolStats.apply(X)) + a.e_y.lin(PoolStats.apply(E)))       # :157-161
+    return newX, newE, new_y
+
+
 def _layer(layer, X, E, y, nm_u8, xm, em, training):
     """layers.py:330-361 (post-LN residual blocks; dropout only in train mode)."""
     drop = (lambda t: F.dropout(t, layer.dropout_p, True)) if training and layer.dropout_p > 0 else (lambda t: t)
-    nX, nE, ny = _node_edge_block(layer.self_attn, X, E, y, nm_u8, xm, em)
+    block = _node_edge_block_improved if layer.self_attn.improved else _node_edge_block
+    nX, nE, ny = block(layer.self_attn, X, E, y, nm_u8, xm, em)
     X = AddLayerNorm.apply(X, drop(nX), layer.normX1.weight, layer.normX1.bias)
     E = AddLayerNorm.apply(E, drop(nE), layer.normE1.weight, layer.normE1.bias)
     y = AddLayerNorm.apply(y, drop(ny), layer.norm_y1.weight, layer.norm_y1.bias)

@@ -17,6 +17,7 @@ class _DenoiserBase(nn.Module):
     def _build(self, n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in, act_fn_out, improved,
                dropout):
         self.n_layers = n_layers
+        self.improved = bool(improved)       # NodeEdgeBlockImproved has no fused inference kernels: forward() always takes train_forward's path
         self.n_head = hidden_dims['n_head']
         self.out_dim_X, self.out_dim_E, self.out_dim_y = output_dims['X'], output_dims['E'], output_dims['y']
         if not isinstance(act_fn_in, nn.ReLU) or not isinstance(act_fn_out, nn.ReLU):
@@ -50,7 +51,7 @@ class _DenoiserBase(nn.Module):
 
     def supports_fused_step(self):
         """da_edge_out_sample (the reverse step's edge half inside the output kernel) is built for 7 edge classes."""
-        return self.out_dim_E == 7 and engine.EDGE_OUT == 'tiles' and engine.FUSED_STEP
+        return self.out_dim_E == 7 and engine.EDGE_OUT == 'tiles' and engine.FUSED_STEP and not self.improved
 
     def _check(self, X):
         if not X.is_cuda:
@@ -65,7 +66,7 @@ class GraphTransformerWithY(_DenoiserBase):
 
     def forward(self, X, E, y, node_mask, step=None):
         self._check(X)
-        if self._differentiable():
+        if self._differentiable() or self.improved:
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask) + (node_mask,)
         pm = self._pack(X.device)
@@ -98,7 +99,7 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
     def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments, step=None):
         assert atom_map_numbers is not None
         self._check(X)
-        if self._differentiable():
+        if self._differentiable() or self.improved:
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments) + (node_mask,)
         pm = self._pack(X.device)

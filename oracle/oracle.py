@@ -340,13 +340,37 @@ def node_edge_block(sd: Dict[str, Tensor], p: str, X, E, y, node_mask, n_head: i
     return newX, newE, new_y
 
 
+def node_edge_block_improved(sd: Dict[str, Tensor], p: str, X, E, y, node_mask, n_head: int):
+    """neuralnet/layers.py:87-164 NodeEdgeBlockImproved.forward: newE = e_out(Y) without the y FiLM; one softmax per head over the
+    head's summed scores."""
+    B, n, dx = X.shape
+    df = dx // n_head
+    xm = node_mask.to(X.dtype)[:, :, None]
+    em = xm[:, :, None, :] * xm[:, None, :, :]
+    Q = _lin(sd, p + '.q', X) * xm
+    K = _lin(sd, p + '.k', X) * xm
+    V = _lin(sd, p + '.v', X) * xm
+    Y = Q[:, :, None, :] * K[:, None, :, :] / math.sqrt(df)
+    Y = Y * (_lin(sd, p + '.e_mul', E) * em + 1) + _lin(sd, p + '.e_add', E) * em
+    newE = _lin(sd, p + '.e_out', Y) * em
+    attn = F.softmax(Y.reshape(B, n, n, n_head, df).sum(-1), dim=2)
+    wV = (attn[..., None] * V.reshape(B, 1, n, n_head, df)).sum(dim=2).reshape(B, n, dx)
+    yx1 = _lin(sd, p + '.y_x_add', y)[:, None, :]
+    yx2 = _lin(sd, p + '.y_x_mul', y)[:, None, :]
+    newX = _lin(sd, p + '.x_out', yx1 + (yx2 + 1) * wV) * xm
+    x_y = F.linear(_stats4(X, 1), sd[p + '.x_y.lin.weight'], sd[p + '.x_y.lin.bias'])
+    e_y = F.linear(_stats4(E, (1, 2)), sd[p + '.e_y.lin.weight'], sd[p + '.e_y.lin.bias'])
+    new_y = _lin(sd, p + '.y_out.2', F.relu(_lin(sd, p + '.y_out.0', y + x_y + e_y)))
+    return newX, newE, new_y
+
+
 def _ln(sd, key, x, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), sd[key + '.weight'], sd[key + '.bias'], eps)
 
 
-def xey_layer(sd, p: str, X, E, y, node_mask, n_head: int):
+def xey_layer(sd, p: str, X, E, y, node_mask, n_head: int, improved: bool = False):
     """neuralnet/layers.py:330-361 XEyTransformerLayer.forward in eval mode (dropout = identity)."""
-    nX, nE, ny = node_edge_block(sd, p + '.self_attn', X, E, y, node_mask, n_head)
+    nX, nE, ny = (node_edge_block_improved if improved else node_edge_block)(sd, p + '.self_attn', X, E, y, node_mask, n_head)
     X = _ln(sd, p + '.normX1', X + nX)
     E = _ln(sd, p + '.normE1', E + nE)
     y = _ln(sd, p + '.norm_y1', y + ny)
@@ -426,7 +450,7 @@ def aligned_inputs(X_in, E_in, src: Tensor, Kx: int, Ke: int):
 
 def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n_head: int,
                      out_dims: Tuple[int, int, int], atom_map_numbers=None, pos_encodings=None,
-                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = '', input_alignment=False, alignment_type='correct'):
+                     mol_assignments=None, p_to_r_skip_connection=False, prefix: str = '', input_alignment=False, alignment_type='correct', improved=False):
     """transformer_model_with_y.py:620-713 (atom-map variant when pos_encodings is given) and
     :74-111 (plain GraphTransformerWithY).  Returns un-masked logits (X, E, y)."""
     Kx, Ke, Ky = out_dims
@@ -445,7 +469,7 @@ def denoiser_forward(sd: Dict[str, Tensor], X, E, y, node_mask, n_layers: int, n
     if pos_encodings is not None:
         Xh = Xh + pos_encodings
     for l in range(n_layers):
-        Xh, Eh, yh = xey_layer(sd, f'{prefix}tf_layers.{l}', Xh, Eh, yh, node_mask, n_head)
+        Xh, Eh, yh = xey_layer(sd, f'{prefix}tf_layers.{l}', Xh, Eh, yh, node_mask, n_head, improved)
     Xo = _lin(sd, prefix + 'mlp_out_X.2', F.relu(_lin(sd, prefix + 'mlp_out_X.0', Xh))) + X_in[..., :Kx]
     Eo = _lin(sd, prefix + 'mlp_out_E.2', F.relu(_lin(sd, prefix + 'mlp_out_E.0', Eh))) + E_in[..., :Ke]
     Eo = Eo * (~torch.eye(n, dtype=torch.bool))[None, :, :, None]

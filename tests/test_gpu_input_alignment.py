@@ -16,11 +16,11 @@ from tests.test_oracle_golden import inalign_weights
 pytestmark = pytest.mark.gpu
 
 
-def build(dims, n_layers, skip, sd=None, seed=45, align='correct', inal=True):
+def build(dims, n_layers, skip, sd=None, seed=45, align='correct', inal=True, improved=False):
     from diffalign_amd.transformer_model_with_y import GraphTransformerWithYAtomMapPosEmb
     m = GraphTransformerWithYAtomMapPosEmb(n_layers, IN_DIMS, dims['hidden_mlp_dims'], dims['hidden_dims'], OUT_DIMS, nn.ReLU(), nn.ReLU(),
                                            dropout=0.0, p_to_r_skip_connection=skip, p_to_r_init=1.0, alignment_type=align,
-                                           input_alignment=inal).eval()
+                                           input_alignment=inal, improved=improved).eval()
     if sd is None:
         sd = init_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
         if skip:
@@ -119,3 +119,38 @@ def test_alignment_type_old_vs_reference_golden_and_training(inal):
     for name in ('skip_scaling', 'skip_scaling_2', 'mlp_in_E.0.weight', 'mlp_out_E.2.weight'):
         want, got = osd[name].grad, dict(m.named_parameters())[name].grad.cpu()
         assert float((got - want).norm()) <= 1e-4 * float(want.norm()) + 1e-6, name
+
+
+def test_improved_block_vs_reference_golden_and_training():
+    """cfg.neuralnet.improved=True (NodeEdgeBlockImproved, layers.py:49-164): no fused kernels -- eval and train both run the fp32 path
+    of train_forward.py (HIP autograd.Functions + library GEMMs).  Logits against the reference's to 2e-4, every parameter gradient
+    against autograd through the oracle to 1e-4; y_e_mul / y_e_add exist in the block but are unused and get no gradient."""
+    from tests.test_oracle_golden import plain_weights_seed45
+    z = load('model_inalign')
+    sd = plain_weights_seed45()
+    m, _ = build(TINY, int(z['n_layers']), True, sd=sd, inal=False, improved=True)
+    assert not m.supports_fused_step()
+    X = torch.cat([F.one_hot(T(z['X_idx']), KX).float(), T(z['X_extra'])], -1)
+    E = F.one_hot(T(z['E_idx']), KE).float()
+    args = (T(z['y_in']), T(z['node_mask']), T(z['am']), T(z['pos']), T(z['mol']))
+    with torch.no_grad():
+        r = m(X.to(D), E.to(D), *[a.to(D) for a in args])
+    for a_, name in ((r[0], 'X'), (r[1], 'E'), (r[2], 'y')):
+        assert (a_.cpu() - T(z[f'improved_skip_{name}'])).abs().max() <= 2e-4, name
+    m.train()
+    rt = m(X.to(D), E.to(D), *[a.to(D) for a in args])
+    osd = {k: v.clone().float().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    o = O.denoiser_forward(osd, X, E, args[0], args[1], int(z['n_layers']), int(z['n_head']), (KX, KE, 1), args[2], args[3], args[4], True,
+                           improved=True)
+    g = torch.Generator().manual_seed(8)
+    wX, wE = torch.randn(o[0].shape, generator=g), torch.randn(o[1].shape, generator=g)
+    ((o[0] * wX).sum() + (o[1] * wE).sum()).backward()
+    ((rt[0] * wX.to(D)).sum() + (rt[1] * wE.to(D)).sum()).backward()
+    for name, p in m.named_parameters():
+        want = osd[name].grad
+        if want is None or float(want.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        err = float((p.grad.cpu() - want).norm()) / (float(want.norm()) + 1e-6)
+        assert err <= 1e-4, (name, err)
+    assert dict(m.named_parameters())['tf_layers.0.self_attn.y_e_mul.weight'].grad is None

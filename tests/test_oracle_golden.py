@@ -158,6 +158,15 @@ def test_model_alignment_type_old():
     close(r[0], z['old_inal_skip_X'], 5e-5); close(r[1], z['old_inal_skip_E'], 5e-5)
 
 
+def test_model_improved_block():
+    """cfg.neuralnet.improved=True: NodeEdgeBlockImproved (layers.py:49-164) inside the atom-map model with the skip connection."""
+    z = load('model_inalign')
+    X, E, y, nm, am, pos, mol = _model_inputs(z)
+    r = O.denoiser_forward(plain_weights_seed45(), X, E, y, nm, int(z['n_layers']), int(z['n_head']), (KX, KE, 1), am, pos, mol, True,
+                           improved=True)
+    close(r[0], z['improved_skip_X'], 5e-5); close(r[1], z['improved_skip_E'], 5e-5); close(r[2], z['improved_skip_y'], 5e-5)
+
+
 def test_model_full_dims_one_layer():
     from tests.golden.common import init_state_dict
     import ast
