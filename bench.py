@@ -151,6 +151,9 @@ def train_main(args, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
+TABLE_PREFETCH = os.environ.get('DA_TABLE_PREFETCH', '1') != '0'   # A/B switch: per-step transition tables prepared beside the previous step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -235,7 +238,8 @@ def main():
         z_t.y = t_arr.float() * 5
         # what sample_one_batch runs per step: denoiser forward with the edge half of posterior / draw / apply_mask drawn inside its
         # output kernel (per-chain counter noise, seeds from `gen`), the node half behind the node output path
-        zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, generator=gen)
+        zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, generator=gen,
+                                        t_int=t if TABLE_PREFETCH else None)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
 

@@ -134,14 +134,18 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                            mol_assignments=noisy_data.mol_assignments)
 
     def reverse_step(self, z_t, t_array, pos_encodings=None, transition_model=None, temperature=(1.0, 1.0), noise=None, chain_seeds=None,
-                     call=0, orig=None, node_masks=None, generator=None, want_logits=False):
+                     call=0, orig=None, node_masks=None, generator=None, want_logits=False, t_int=None):
         """One reverse step p(z_s | z_t) (diffusion/sampling.py:76-86,165-178): denoiser forward + posterior + categorical draw +
         apply_mask.  With 7 edge classes the edge half is drawn inside the denoiser's output kernel (da_edge_out_sample; the
         (B,n,n,7) logits and noise tensors never reach HBM); otherwise forward() + helpers.posterior_sample.  Both give the same
-        z_s for the same noise, bit for bit.  Returns (zs_X, zs_E, pred); pred.E is None in the fused form (want_logits=True: separate form)."""
+        z_s for the same noise, bit for bit.  Returns (zs_X, zs_E, pred); pred.E is None in the fused form (want_logits=True: separate form).
+        `t_int`: the step number when all graphs share it (then t_array is not read for the tables)."""
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
-        Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
+        if t_int is not None:        # every graph is at step t_int (the sampling loop): tables prepared beside the previous step
+            Qt, Qsb, Qtb = tm.step_tables(int(t_int), z_t.X.shape[0], prefetch=int(t_int) - 1)
+        else:
+            Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
         if self._net().supports_fused_step() and not self._net()._differentiable() and not want_logits:
             ctx = helpers.reverse_step_ctx(z_t, Qt, Qsb, Qtb, temperature, noise, chain_seeds, call, orig, node_masks, generator)
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings, step=ctx)

@@ -17,6 +17,7 @@ N_XSTAT_CHUNKS = 8
 N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
 STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
 Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
+EARLY_QKV0 = os.environ.get('DA_EARLY_QKV0', '1') != '0'   # layer 0's q/k/v and Xtoy term behind the node input path (A/B switch)
 FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
 SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
@@ -284,28 +285,34 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2):
+def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre=None):
     """The layer stack with three streams.  Between two edge kernels two chains run: the y branch (y_update(l) needs the Etoy
     statistics the edge kernel of layer l leaves, then the FiLM vectors of layer l+1: ~100 us, 64 small workgroups) and the node chain
     (merge, node tail of layer l, q/k/v of layer l+1: ~80 us).  The LONGER one, the y branch, stays on the caller's stream right
     behind the edge kernel and in front of the next one, so that it never waits for a cross-stream event (each costs 15-30 us of
     idle GPU when it is on the critical path); the node chain runs on a side stream, the Xtoy statistics of the next layer on a
-    third.  Every buffer is allocated on the caller's stream and stays referenced until that stream has joined its last reader."""
+    third.  Every buffer is allocated on the caller's stream and stays referenced until that stream has joined its last reader.
+    `pre` = (Qm, kvf, xst, xy) of layer 0 when the input stage already produced them behind the node features (model_forward)."""
     dev = Xh.device
     ev_x = None                                      # q/k/v of the coming layer complete (side stream)
-    xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
-    xy = torch.empty(B, pm.dy, device=dev)
-    Qm, kvf = _qkv_buffers(pm, B, n, dev)
-    x_ready = main.record_event()
-    with torch.cuda.stream(side2):                   # Xtoy statistics of layer 0's input and their x_y.lin term
-        side2.wait_event(x_ready)
-        node_stats(pm, Xh, B, n, out=xst)
-        y_pre(pm, pm.layers[0], xst, B, n, xy)
-        xs_done = side2.record_event()
-    _qkv(pm, pm.layers[0], Xh, nm, B, n, out=(Qm, kvf))
-    if y_done0 is not None:
-        main.wait_event(y_done0)                     # FiLM vectors of layer 0 (y stream of the input stage)
-    main.wait_event(xs_done)
+    if pre is not None:
+        Qm, kvf, xst, xy = pre
+        if y_done0 is not None:
+            main.wait_event(y_done0)                 # FiLM vectors of layer 0 (y stream of the input stage)
+    else:
+        xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
+        xy = torch.empty(B, pm.dy, device=dev)
+        Qm, kvf = _qkv_buffers(pm, B, n, dev)
+        x_ready = main.record_event()
+        with torch.cuda.stream(side2):               # Xtoy statistics of layer 0's input and their x_y.lin term
+            side2.wait_event(x_ready)
+            node_stats(pm, Xh, B, n, out=xst)
+            y_pre(pm, pm.layers[0], xst, B, n, xy)
+            xs_done = side2.record_event()
+        _qkv(pm, pm.layers[0], Xh, nm, B, n, out=(Qm, kvf))
+        if y_done0 is not None:
+            main.wait_event(y_done0)                 # FiLM vectors of layer 0 (y stream of the input stage)
+        main.wait_event(xs_done)
     keep = []
     for li, lw in enumerate(pm.layers):
         nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
@@ -378,23 +385,37 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         src = align_src.contiguous() if align_src is not None else torch.empty(B, n, dtype=torch.int32, device=dev)
         am64, mol64 = atom_map_numbers.contiguous(), mol_assignments.contiguous()
 
-    def node_input_path():
+    # with the three-stream layer stack, what layer 0 needs from the node features alone (q/k/v, the Xtoy statistics and their x_y.lin
+    # term) follows them on their stream, beside the edge input stage; the alignment index, which only the output stage reads, goes last
+    early0 = side is not None and side2 is not None and Y_ON_MAIN and EARLY_QKV0
+    pre = (*_qkv_buffers(pm, B, n, dev), torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev), torch.empty(B, pm.dy, device=dev)) if early0 else None
+
+    def node_features():
         _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
         _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
         L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), L.stream()), 'da_x_in_finish')
+        if pre is not None:
+            node_stats(pm, Xh, B, n, out=pre[2])
+            y_pre(pm, pm.layers[0], pre[2], B, n, pre[3])
+            _qkv(pm, pm.layers[0], Xh, nm, B, n, out=(pre[0], pre[1]))
+
+    def alignment():
         if use_skip and align_src is None:
             L.check(lib.da_align_index(L.ptr(am64, torch.int64), L.ptr(mol64, torch.int64), L.ptr(src), _i(B), _i(n), L.stream()),
                     'da_align_index')
 
-    xin_done = None
+    xin_done = align_done = None
     if side2 is None:
-        node_input_path()
+        node_features()
+        alignment()
     else:
         in_ready = main.record_event()
         with torch.cuda.stream(side2):
             side2.wait_event(in_ready)
-            node_input_path()
+            node_features()
             xin_done = side2.record_event()
+            alignment()
+            align_done = side2.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
     sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
@@ -415,16 +436,16 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             y_input_path()
             layer_film(pm, pm.layers[0], yh, B, film0)
             y_done0 = side.record_event()
-    if xin_done is not None:
-        main.wait_event(xin_done)
     # ---- layers
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
+    if xin_done is not None:
+        main.wait_event(xin_done)
     if side is None:
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
         if Y_ON_MAIN:
-            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2)
+            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre=pre)
         else:
             # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
             film, y_done = film0, y_done0
@@ -492,6 +513,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             node_output_path()
             xout_done = side2.record_event()
     Eo = torch.empty(B, n, n, pm.ke, device=dev) if step is None else None
+    if align_done is not None:
+        main.wait_event(align_done)                  # the skip connection's index (node stream of the input stage; long done)
     if step is not None:
         c = step
         L.check(lib.da_edge_out_sample(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2),

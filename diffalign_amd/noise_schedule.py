@@ -138,6 +138,46 @@ class DiffusionTransition:
     def get_limit_dist(self):
         return PlaceHolder(X=self.x_limit, E=self.e_limit, y=self.y_limit)
 
+    # -- one reverse step whose B graphs share the step number (the sampling loop): the three per-graph table sets a step needs,
+    # built by six small copies; the set of the NEXT step is prepared on a stream of its own while the current step runs, so that the
+    # dozen gather kernels of get_Qt / get_Qt_bar (6 us each, serial, in front of every step) leave the critical path
+    _PREFETCH = {}
+
+    def _step_tables_now(self, t: int, B: int):
+        rep = lambda Q, i: Q[i].expand(B, -1, -1).contiguous()
+        eye = (lambda: torch.eye(self.e_classes, device=self.Qts_x.device)[None].repeat(B, 1, 1))
+        E = (lambda Q, i: rep(Q, i)) if self.diffuse_edges else (lambda Q, i: eye())
+        return (PlaceHolder(X=rep(self.Qts_x, t), E=E(self.Qts_e, t), y=None),
+                PlaceHolder(X=rep(self.Qt_bars_x, t - 1), E=E(self.Qt_bars_e, t - 1), y=None),
+                PlaceHolder(X=rep(self.Qt_bars_x, t), E=E(self.Qt_bars_e, t), y=None))
+
+    def step_tables(self, t: int, B: int, prefetch: Optional[int] = None):
+        """(Q_t, Qbar_{t-1}, Qbar_t) as (B,K,K) tables for step t shared by all B graphs (== get_Qt / get_Qt_bar on a constant t
+        array, without the y tables).  `prefetch`: the step number the caller will ask for next."""
+        dev = self.Qts_x.device
+        cache = self.__dict__.setdefault('_step_cache', {})
+        hit = cache.pop((t, B), None)
+        capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if hit is not None and not capturing:
+            tabs, ev = hit
+            cur = torch.cuda.current_stream(dev)
+            if not ev.query():                                       # usually long done; a wait that is enqueued costs ~30 us of idle GPU even then
+                cur.wait_event(ev)
+            for ph in tabs:
+                ph.X.record_stream(cur); ph.E.record_stream(cur)
+        else:
+            tabs = self._step_tables_now(t, B)
+        cache.clear()                                                # at most one prepared step is kept
+        if prefetch is not None and prefetch >= 1 and dev.type == 'cuda' and not capturing:
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            if key not in DiffusionTransition._PREFETCH:
+                DiffusionTransition._PREFETCH[key] = torch.cuda.Stream(device=dev)
+            st = DiffusionTransition._PREFETCH[key]
+            with torch.cuda.stream(st):
+                nxt = self._step_tables_now(prefetch, B)
+                cache[(prefetch, B)] = (nxt, st.record_event())
+        return tabs
+
 
 def _mix_family(T, u, betas, abar):
     K = u.shape[-1]

@@ -85,7 +85,7 @@ class SamplingMixin:
             record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)
             if not record and not guided:                                  # the whole step as one call (fused where the model allows)
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
-                                                orig=dense_data, node_masks=masks, **nz(step=True))
+                                                orig=dense_data, node_masks=masks, t_int=t_int, **nz(step=True))
                 z_t.X, z_t.E = zsX, zsE
                 z_t = fix(z_t)
                 continue

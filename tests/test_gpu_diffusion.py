@@ -159,3 +159,18 @@ def test_empty_batch_and_bad_args():
     with pytest.raises(L.DiffAlignHipError):
         PlaceHolder(X=torch.zeros(1, 2, 3), E=torch.zeros(1, 2, 2, 2), y=torch.zeros(1, 1),
                     node_mask=torch.ones(1, 2, dtype=torch.bool)).mask()     # CPU tensors: no fallback
+
+
+def test_step_tables_equal_gathered_tables_with_and_without_prefetch():
+    """DiffusionTransition.step_tables (one step number for the whole batch; the next step's set prepared on its own stream) ==
+    get_Qt / get_Qt_bar on a constant t array."""
+    for fam in ('abs', 'mar'):
+        tm = _transition(fam)
+        B = 5
+        for t in (10, 9, 8, 3, 1):                               # 9 and 8 come from the prefetch of the step before, 3 and 1 do not
+            Qt, Qsb, Qtb = tm.step_tables(t, B, prefetch=t - 1)
+            t_arr = torch.full((B, 1), t, dtype=torch.long, device=D)
+            for got, want in ((Qt, tm.get_Qt(t_arr)), (Qsb, tm.get_Qt_bar(t_arr - 1)), (Qtb, tm.get_Qt_bar(t_arr))):
+                assert torch.equal(got.X, want.X) and torch.equal(got.E, want.E)
+                assert got.X.is_contiguous() and got.E.is_contiguous()
+        assert len(tm._step_cache) == 0                          # t = 1 prepares nothing
