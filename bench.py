@@ -151,7 +151,7 @@ def train_main(args, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
-TABLE_PREFETCH = os.environ.get('DA_TABLE_PREFETCH', '1') != '0'   # A/B switch: per-step transition tables prepared beside the previous step
+TABLE_PREFETCH = os.environ.get('DA_TABLE_PREFETCH', '1') != '0'   # A/B switch: per-step transition tables as slices of tables laid out once (reverse_step t_int=)
 
 
 def main():
@@ -232,13 +232,20 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     state = {'t': 50}
 
+    # as sample_one_batch: one seed per chain from the generator, step numbers and y inputs laid out once
+    seeds = torch.randint(0, 2 ** 62, (B,), device=dev, generator=gen)
+    all_t = torch.arange(51, device=dev)[:, None, None].expand(-1, B, 1).contiguous()
+    all_y = all_t.float() * 5
+    state['call'] = 0
+
     def step():
         t = state['t']
-        t_arr = torch.full((B, 1), t, dtype=torch.long, device=dev)
-        z_t.y = t_arr.float() * 5
+        t_arr = all_t[t]
+        z_t.y = all_y[t]
+        state['call'] += 1
         # what sample_one_batch runs per step: denoiser forward with the edge half of posterior / draw / apply_mask drawn inside its
         # output kernel (per-chain counter noise, seeds from `gen`), the node half behind the node output path
-        zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, generator=gen,
+        zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, chain_seeds=seeds, call=state['call'],
                                         t_int=t if TABLE_PREFETCH else None)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50

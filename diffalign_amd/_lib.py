@@ -48,7 +48,7 @@ SIGNATURES = {
     'da_edge_in_blob_bytes': 'q:ii',
     'da_edge_out_blob_bytes': 'q:ii',
     'da_kv_frag_bytes': 'q:iii',
-    'da_x_post_blob_bytes': 'q:ii',
+    'da_x_post_blob_bytes': 'q:ii', 'da_x_in_blob_bytes': 'q:iii', 'da_x_in': 'i:pippppiiip',
     'da_linear': 'i:pipipppiiiiip',
     'da_x_post': 'i:pppppiiip',
     'da_add_layernorm': 'i:pppppiip',

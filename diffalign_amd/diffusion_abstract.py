@@ -142,8 +142,8 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         `t_int`: the step number when all graphs share it (then t_array is not read for the tables)."""
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
-        if t_int is not None:        # every graph is at step t_int (the sampling loop): tables prepared beside the previous step
-            Qt, Qsb, Qtb = tm.step_tables(int(t_int), z_t.X.shape[0], prefetch=int(t_int) - 1)
+        if t_int is not None:        # every graph is at step t_int (the sampling loop): slices of tables laid out once per batch size
+            Qt, Qsb, Qtb = tm.step_tables(int(t_int), z_t.X.shape[0])
         else:
             Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
         if self._net().supports_fused_step() and not self._net()._differentiable() and not want_logits:

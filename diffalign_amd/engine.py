@@ -17,6 +17,7 @@ N_XSTAT_CHUNKS = 8
 N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
 STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
 Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
+FUSED_X_IN = os.environ.get('DA_FUSED_X_IN', '1') != '0'   # node input stage as one kernel (da_x_in) instead of two da_linear + da_x_in_finish
 EARLY_QKV0 = os.environ.get('DA_EARLY_QKV0', '1') != '0'   # layer 0's q/k/v and Xtoy term behind the node input path (A/B switch)
 FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
@@ -63,6 +64,9 @@ class PackedModel:
             raise L.DiffAlignHipError(f'hidden dims (de={self.de}, dx={self.dx}, dim_ffE={self.dffe}) are not built into '
                                       'libdiffalign_hip.so; built: (64,256,128) and (32,64,64)')
         self.in_X = [bw('mlp_in_X.0.weight'), f32(g('mlp_in_X.0.bias')), bw('mlp_in_X.2.weight'), f32(g('mlp_in_X.2.bias'))]
+        # fused node input stage (da_x_in) where its widths are built
+        self.x_in = (pack.x_in_blob(sd, prefix).to(dev)
+                     if FUSED_X_IN and L.lib().da_x_in_blob_bytes(_i(g('mlp_in_X.0.weight').shape[1]), _i(self.hx), _i(self.dx)) > 0 else None)
         self.in_y = [f32(g('mlp_in_y.0.weight')), f32(g('mlp_in_y.0.bias')), f32(g('mlp_in_y.2.weight')), f32(g('mlp_in_y.2.bias'))]
         self.in_E = pack.edge_in_blob(sd, prefix).to(dev)
         self.out_X = [bw('mlp_out_X.0.weight'), f32(g('mlp_out_X.0.bias')), bw('mlp_out_X.2.weight'), f32(g('mlp_out_X.2.bias'))]
@@ -391,9 +395,13 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     pre = (*_qkv_buffers(pm, B, n, dev), torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev), torch.empty(B, pm.dy, device=dev)) if early0 else None
 
     def node_features():
-        _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
-        _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
-        L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), L.stream()), 'da_x_in_finish')
+        if pm.x_in is not None:
+            L.check(lib.da_x_in(L.ptr(X), _i(pm.dx_in), L.ptr(nm), L.ptr(pos), L.ptr(pm.x_in), L.ptr(Xh), _i(R), _i(pm.hx), _i(pm.dx),
+                                L.stream()), 'da_x_in')
+        else:
+            _linear(X, pm.dx_in, pm.in_X[0], pm.in_X[1], None, h0, pm.hx, R, pm.hx, pm.dx_in, True)
+            _linear(h0, pm.hx, pm.in_X[2], pm.in_X[3], None, Xh, pm.dx, R, pm.dx, pm.hx, True)
+            L.check(lib.da_x_in_finish(L.ptr(Xh), L.ptr(nm), L.ptr(pos), _i(R), _i(pm.dx), L.stream()), 'da_x_in_finish')
         if pre is not None:
             node_stats(pm, Xh, B, n, out=pre[2])
             y_pre(pm, pm.layers[0], pre[2], B, n, pre[3])

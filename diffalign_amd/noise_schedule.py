@@ -138,10 +138,13 @@ class DiffusionTransition:
     def get_limit_dist(self):
         return PlaceHolder(X=self.x_limit, E=self.e_limit, y=self.y_limit)
 
-    # -- one reverse step whose B graphs share the step number (the sampling loop): the three per-graph table sets a step needs,
-    # built by six small copies; the set of the NEXT step is prepared on a stream of its own while the current step runs, so that the
-    # dozen gather kernels of get_Qt / get_Qt_bar (6 us each, serial, in front of every step) leave the critical path
-    _PREFETCH = {}
+    # -- one reverse step whose B graphs share the step number (the sampling loop): the three per-graph table sets a step needs.
+    # get_Qt / get_Qt_bar cost a dozen gather kernels (6 us each, serial, in front of every step); here every step's (B,K,K) tables
+    # are laid out once per batch size, (T+1, B, K, K) per family, and a step takes slices: no kernel, no stream, no event.
+    # (Preparing only the next step's set on a side stream was tried first: handing its tensors to the caller's stream costs one
+    # allocator event record per tensor on that stream, ~6 us each -- as much as the gathers it saved.)
+    STEP_TABLE_BYTES_MAX = 512 << 20
+    STEP_STATS = {'sliced': 0, 'built': 0}                   # how step_tables was served
 
     def _step_tables_now(self, t: int, B: int):
         rep = lambda Q, i: Q[i].expand(B, -1, -1).contiguous()
@@ -151,32 +154,25 @@ class DiffusionTransition:
                 PlaceHolder(X=rep(self.Qt_bars_x, t - 1), E=E(self.Qt_bars_e, t - 1), y=None),
                 PlaceHolder(X=rep(self.Qt_bars_x, t), E=E(self.Qt_bars_e, t), y=None))
 
-    def step_tables(self, t: int, B: int, prefetch: Optional[int] = None):
+    def step_tables(self, t: int, B: int):
         """(Q_t, Qbar_{t-1}, Qbar_t) as (B,K,K) tables for step t shared by all B graphs (== get_Qt / get_Qt_bar on a constant t
-        array, without the y tables).  `prefetch`: the step number the caller will ask for next."""
-        dev = self.Qts_x.device
-        cache = self.__dict__.setdefault('_step_cache', {})
-        hit = cache.pop((t, B), None)
-        capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-        if hit is not None and not capturing:
-            tabs, ev = hit
-            cur = torch.cuda.current_stream(dev)
-            if not ev.query():                                       # usually long done; a wait that is enqueued costs ~30 us of idle GPU even then
-                cur.wait_event(ev)
-            for ph in tabs:
-                ph.X.record_stream(cur); ph.E.record_stream(cur)
-        else:
-            tabs = self._step_tables_now(t, B)
-        cache.clear()                                                # at most one prepared step is kept
-        if prefetch is not None and prefetch >= 1 and dev.type == 'cuda' and not capturing:
-            key = dev.index if dev.index is not None else torch.cuda.current_device()
-            if key not in DiffusionTransition._PREFETCH:
-                DiffusionTransition._PREFETCH[key] = torch.cuda.Stream(device=dev)
-            st = DiffusionTransition._PREFETCH[key]
-            with torch.cuda.stream(st):
-                nxt = self._step_tables_now(prefetch, B)
-                cache[(prefetch, B)] = (nxt, st.record_event())
-        return tabs
+        array, without the y tables)."""
+        T1 = self.Qts_x.shape[0]
+        assert 1 <= t < T1
+        nbytes = 2 * T1 * B * 4 * (self.x_classes ** 2 + self.e_classes ** 2)
+        if nbytes > self.STEP_TABLE_BYTES_MAX or not self.diffuse_edges:
+            DiffusionTransition.STEP_STATS['built'] += 1
+            return self._step_tables_now(t, B)
+        cache = self.__dict__.setdefault('_step_all', {})
+        if B not in cache:
+            if self.Qts_x.is_cuda and torch.cuda.is_current_stream_capturing():
+                return self._step_tables_now(t, B)
+            cache.clear()                                            # one batch size at a time
+            rep = lambda Q: Q[:, None].expand(-1, B, -1, -1).contiguous()
+            cache[B] = (rep(self.Qts_x), rep(self.Qts_e), rep(self.Qt_bars_x), rep(self.Qt_bars_e))
+        qx, qe, bx, be = cache[B]
+        DiffusionTransition.STEP_STATS['sliced'] += 1
+        return (PlaceHolder(X=qx[t], E=qe[t], y=None), PlaceHolder(X=bx[t - 1], E=be[t - 1], y=None), PlaceHolder(X=bx[t], E=be[t], y=None))
 
 
 def _mix_family(T, u, betas, abar):

@@ -89,6 +89,20 @@ def x_post_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
     return _blob(frags, params)
 
 
+def x_in_blob(sd, prefix='') -> torch.Tensor:
+    """Blob for da_x_in (mlp_in_X).  Layout = XInCfg in csrc/k_x_in.hip: W0 fragments [hidden/32][ceil(dx_in/16)] in natural k order
+    (K zero padded), W1 fragments [dx/32][hidden/16] in C order, then b0, b1."""
+    g = lambda k: sd[prefix + k].detach().float().cpu()
+    W0, W1 = g('mlp_in_X.0.weight'), g('mlp_in_X.2.weight')
+    hx, dx_in = W0.shape
+    dx = W1.shape[0]
+    ks0 = (dx_in + 15) // 16
+    W0p = _pad2(W0, hx, 16 * ks0)
+    frags = [_frag(W0p, ht, s, False) for ht in range(hx // 32) for s in range(ks0)]
+    frags += [_frag(W1, mt, s, True) for mt in range(dx // 32) for s in range(hx // 16)]
+    return _blob(frags, [g('mlp_in_X.0.bias'), g('mlp_in_X.2.bias')])
+
+
 def edge_in_blob(sd, prefix='') -> torch.Tensor:
     g = lambda k: sd[prefix + k].detach().float().cpu()
     W0, W1 = g('mlp_in_E.0.weight'), g('mlp_in_E.2.weight')

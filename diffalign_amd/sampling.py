@@ -28,6 +28,10 @@ class SamplingMixin:
         kx, ke = dense_data.X.shape[-1], dense_data.E.shape[-1]
         calls = [0]
 
+        if chain_seeds is None and noise_fn is None:
+            # no explicit noise: one seed per chain from torch's generator, once; every draw of the chain is then counter noise of
+            # (seed, call index) -- the same distribution as fresh seeds per step without two generator kernels in front of each step
+            chain_seeds = torch.randint(0, 2 ** 62, (B,), device=device)
         if chain_seeds is not None:
             assert noise_fn is None and chain_seeds.shape == (B,)
             chain_seeds = chain_seeds.to(device=device, dtype=torch.int64)
@@ -78,9 +82,12 @@ class SamplingMixin:
             cond_free = graph.get_node_masks(dense_data, self.dataset_info.atom_decoder, self.dataset_info.bond_decoder,
                                              self.cfg.diffusion.mask_nodes, self.cfg.diffusion.mask_edges, include_supernode=False)
         log_every_t = int(getattr(getattr(self.cfg, 'train', None), 'log_every_t', 1) or 1)
+        # step numbers and the y input of every step, laid out once (a fill, a cast and a multiply per step otherwise)
+        all_t = torch.arange(T_eval + 1, device=device)[:, None, None].expand(-1, B, 1).contiguous()
+        all_y = all_t.float() * eval_step_size
         for t_int in range(T_eval, 0, -1):
-            t_array = torch.full((B, 1), t_int, dtype=torch.long, device=device)
-            z_t.y = t_array.float() * eval_step_size                       # raw train-scale step index (sampling.py:76)
+            t_array = all_t[t_int]
+            z_t.y = all_y[t_int]                                           # raw train-scale step index (sampling.py:76)
             s_int = t_int - 1
             record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)
             if not record and not guided:                                  # the whole step as one call (fused where the model allows)

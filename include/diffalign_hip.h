@@ -201,6 +201,7 @@ long long da_edge_in_blob_bytes(int de, int he);
 long long da_edge_out_blob_bytes(int de, int he);
 long long da_kv_frag_bytes(int B, int n, int dx);
 long long da_x_post_blob_bytes(int dx, int dffx);           /* -1 when the shape is not built */
+long long da_x_in_blob_bytes(int dx_in, int hx, int dx);    /* -1 when the shape is not built */
 
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (* rowmask): every nn.Linear of the node path -- mlp_in_X / mlp_out_X
  * (transformer_model_with_y.py:584-585,602-603), q/k/v/x_out (layers.py:217-218,256,273), linX1/linX2 (layers.py:349).
@@ -214,6 +215,12 @@ int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float
  * blob = diffalign_amd/pack.py x_post_blob (XPostCfg layout).  Built: (dx, dim_ffX) = (256,256), (64,64). */
 int da_x_post(const float* newX_in, const float* X, const uint8_t* node_mask, const void* blob, float* X_out, int rows, int dx,
               int dffx, void* stream);
+
+/* Node input stage, fused: X_h = encode_no_element(relu(mlp_in_X.2(relu(mlp_in_X.0(X)))) * mask) + pos_encodings
+ * (transformer_model_with_y.py:584-585, 661, 666).  X (rows, dx_in) fp32 row-major with dx_in <= 96, pos (rows, dx) or NULL,
+ * blob = diffalign_amd/pack.py x_in_blob (XInCfg layout).  Built: (hidden_mlp X, dx) = (256,256), (64,64). */
+int da_x_in(const float* X, int dx_in, const uint8_t* node_mask, const float* pos, const void* blob, float* X_h, int rows, int hx, int dx,
+            void* stream);
 
 /* out = LayerNorm(a + b) * gamma + beta, eps 1e-5: normX1 / normX2 (layers.py:341,351). b may be NULL. */
 int da_add_layernorm(const float* a, const float* b, const float* gamma, const float* beta, float* out, int rows, int D,

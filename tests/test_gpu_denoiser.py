@@ -272,3 +272,55 @@ def test_x_post_vs_torch(dims):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize('dims,dx_in,with_pos', [(FULL, 37, True), (FULL, 66, False), (TINY, 37, True), (TINY, 29, False), (FULL, 96, True)],
+                         ids=['full37', 'full66_nopos', 'tiny37', 'tiny29_nopos', 'full96'])
+def test_x_in_vs_torch_and_unfused(dims, dx_in, with_pos):
+    """da_x_in (mlp_in_X + hidden mask with encode_no_element + positional encodings, one kernel) against the same chain in fp32 torch
+    and against the unfused form (two da_linear + da_x_in_finish); rows not a tile multiple, masked rows, an input width that is
+    not a multiple of 16, an all-zero hidden row."""
+    from diffalign_amd import pack, _lib as L
+    import ctypes as C
+    dx, hx = dims['hidden_dims']['dx'], dims['hidden_mlp_dims']['X']
+    g = torch.Generator().manual_seed(6)
+    R = 5 * 37 + 3
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    sd = {'mlp_in_X.0.weight': rnd(hx, dx_in) / math.sqrt(dx_in), 'mlp_in_X.0.bias': rnd(hx) * 0.1,
+          'mlp_in_X.2.weight': rnd(dx, hx) / math.sqrt(hx), 'mlp_in_X.2.bias': rnd(dx) * 0.1}
+    X = rnd(R, dx_in)
+    mask = torch.rand(R, generator=g) > 0.2
+    mask[0] = True
+    pos = rnd(R, dx) if with_pos else None
+    hid = F.relu(F.linear(F.relu(F.linear(X, sd['mlp_in_X.0.weight'], sd['mlp_in_X.0.bias'])), sd['mlp_in_X.2.weight'], sd['mlp_in_X.2.bias']))
+    ref = hid * mask[:, None]
+    ref[ref.sum(-1) == 0, 0] = 1.0
+    if pos is not None:
+        ref = ref + pos
+    assert int(L.lib().da_x_in_blob_bytes(C.c_int(dx_in), C.c_int(hx), C.c_int(dx))) == pack.x_in_blob(sd).numel()
+    blob = pack.x_in_blob(sd).to(D)
+    out = torch.full((R, dx), float('nan'), device=D)
+    Xd, m = X.to(D), L.as_u8(mask.to(D))
+    L.check(L.lib().da_x_in(L.ptr(Xd), C.c_int(dx_in), L.ptr(m), L.ptr(pos.to(D)) if with_pos else L.ptr(None), L.ptr(blob), L.ptr(out),
+                            C.c_int(R), C.c_int(hx), C.c_int(dx), L.stream()), 'da_x_in')
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    assert torch.equal(out.cpu()[~mask], ref[~mask])                      # masked rows: exactly e_0 (+ pos)
+    # the unfused form on the same bf16 weights: same operand rounding, different summation order
+    from diffalign_amd.engine import _linear
+    W0, W1 = pack.bf16_weight(sd['mlp_in_X.0.weight']).to(D), pack.bf16_weight(sd['mlp_in_X.2.weight']).to(D)
+    h0, un = torch.empty(R, hx, device=D), torch.empty(R, dx, device=D)
+    _linear(Xd, dx_in, W0, sd['mlp_in_X.0.bias'].to(D), None, h0, hx, R, hx, dx_in, True)
+    _linear(h0, hx, W1, sd['mlp_in_X.2.bias'].to(D), None, un, dx, R, dx, hx, True)
+    L.check(L.lib().da_x_in_finish(L.ptr(un), L.ptr(m), L.ptr(pos.to(D)) if with_pos else L.ptr(None), C.c_int(R), C.c_int(dx), L.stream()), 'fin')
+    assert (out - un).abs().max() <= 2e-3 * un.abs().max(), float((out - un).abs().max())
+
+
+def test_x_in_refuses_unbuilt_widths():
+    from diffalign_amd import _lib as L
+    import ctypes as C
+    assert int(L.lib().da_x_in_blob_bytes(C.c_int(97), C.c_int(256), C.c_int(256))) == -1
+    assert int(L.lib().da_x_in_blob_bytes(C.c_int(37), C.c_int(96), C.c_int(256))) == -1
+    x = torch.zeros(32, 37, device=D); m = torch.ones(32, dtype=torch.uint8, device=D); o = torch.zeros(32, 96, device=D)
+    rc = L.lib().da_x_in(L.ptr(x), C.c_int(37), L.ptr(m), L.ptr(None), L.ptr(x), L.ptr(o), C.c_int(32), C.c_int(96), C.c_int(96), L.stream())
+    assert rc != 0 and 'not built' in L.last_error()

@@ -161,16 +161,18 @@ def test_empty_batch_and_bad_args():
                     node_mask=torch.ones(1, 2, dtype=torch.bool)).mask()     # CPU tensors: no fallback
 
 
-def test_step_tables_equal_gathered_tables_with_and_without_prefetch():
-    """DiffusionTransition.step_tables (one step number for the whole batch; the next step's set prepared on its own stream) ==
-    get_Qt / get_Qt_bar on a constant t array."""
+def test_step_tables_equal_gathered_tables():
+    """DiffusionTransition.step_tables (one step number for the whole batch: slices of tables laid out once per batch size, or built
+    inline beyond the memory cap) == get_Qt / get_Qt_bar on a constant t array."""
+    from diffalign_amd.noise_schedule import DiffusionTransition
     for fam in ('abs', 'mar'):
         tm = _transition(fam)
-        B = 5
-        for t in (10, 9, 8, 3, 1):                               # 9 and 8 come from the prefetch of the step before, 3 and 1 do not
-            Qt, Qsb, Qtb = tm.step_tables(t, B, prefetch=t - 1)
-            t_arr = torch.full((B, 1), t, dtype=torch.long, device=D)
-            for got, want in ((Qt, tm.get_Qt(t_arr)), (Qsb, tm.get_Qt_bar(t_arr - 1)), (Qtb, tm.get_Qt_bar(t_arr))):
-                assert torch.equal(got.X, want.X) and torch.equal(got.E, want.E)
-                assert got.X.is_contiguous() and got.E.is_contiguous()
-        assert len(tm._step_cache) == 0                          # t = 1 prepares nothing
+        for cap in (DiffusionTransition.STEP_TABLE_BYTES_MAX, 0):
+            tm.STEP_TABLE_BYTES_MAX = cap
+            for B in (5, 3):
+                for t in (10, 9, 3, 1):
+                    Qt, Qsb, Qtb = tm.step_tables(t, B)
+                    t_arr = torch.full((B, 1), t, dtype=torch.long, device=D)
+                    for got, want in ((Qt, tm.get_Qt(t_arr)), (Qsb, tm.get_Qt_bar(t_arr - 1)), (Qtb, tm.get_Qt_bar(t_arr))):
+                        assert torch.equal(got.X, want.X) and torch.equal(got.E, want.E)
+                        assert got.X.is_contiguous() and got.E.is_contiguous()
