@@ -3,6 +3,7 @@
 // LDS, one wave per query row (b,i), 32-pair tiles; both orientations (i,j) and (j,i) are evaluated by the same wave
 // so the symmetrisation needs no second pass over the edge tensor.
 #include "mfma_util.h"
+#include "edge_in_layout.h"
 #include "diffusion_dev.h"
 
 template <int DE, int HE>
@@ -169,17 +170,20 @@ __global__ void __launch_bounds__(64) k_edge_in_table(int de_in, const uint4* __
   }
 }
 
-constexpr int IN_HIST = 16;                          // ints per graph in the class histogram (de_in + 2 <= 10 used)
 // One workgroup per pair of mirrored 32x32 tiles (it <= jt) of one graph.  Both tiles are read row-wise (coalesced) and met
 // in LDS; the workgroup (1) checks that they mirror each other bit for bit and that every pair is one-hot or all zero,
 // clearing flags[b] / flags[B + b] otherwise (all 2B flags must be 1 on entry), (2) writes both output tiles from
 // the table as if the graph passed: k_edge_in, launched afterwards, rewrites the graphs whose flags were cleared, and
 // (3) counts the graph's pairs per table row in hist[b][.] (zero on entry): the pooled statistics of the hidden tensor
 // follow from the counts and the table (k_e_stats_table) without another pass over it.
-template <int DE>
+// CLS_ONLY: instead of the hidden rows, write the table row number of every pair into cls_map[b][i][j] (one byte per pair): the
+// first edge layer then takes its input rows from the table itself (da_edge_layer_table) and the hidden tensor of the graphs that
+// pass is never written or read.
+template <int DE, bool CLS_ONLY>
 __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__ E_in, int de_in, const uint8_t* __restrict__ nm,
                                                        const uint4* __restrict__ T, uint4* __restrict__ E_out, int n,
-                                                       uint8_t* __restrict__ flags, int* __restrict__ hist) {
+                                                       uint8_t* __restrict__ flags, int* __restrict__ hist,
+                                                       uint8_t* __restrict__ cls_map) {
   constexpr int Q = DE / 8;                            // 16-byte words per pair
   int it, jt;
   tri_tile(blockIdx.x, (n + 31) / 32, it, jt);
@@ -242,6 +246,19 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x < de_in + 2 && sh[threadIdx.x]) atomicAdd(&hist[b * IN_HIST + threadIdx.x], sh[threadIdx.x] * (jt != it ? 2 : 1));
+  if (CLS_ONLY) {
+    uint8_t* cb = cls_map + (size_t)b * n * n;
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+      const int ri = t >> 5, cj = t & 31;
+      const int i = it * 32 + ri, j = jt * 32 + cj;
+      if (i < n && j < n) cb[(size_t)i * n + j] = cls[ri][cj];
+      if (jt != it) {                                  // tile (jt, it): row j = jt*32 + ri, column i = it*32 + cj
+        const int j2 = jt * 32 + ri, i2 = it * 32 + cj;
+        if (i2 < n && j2 < n) cb[(size_t)j2 * n + i2] = cls[cj][ri];
+      }
+    }
+    return;
+  }
   const int p = threadIdx.x / Q, q = threadIdx.x % Q;  // Q = 8: 32 pairs x 8 words per pass
   if (p < 32) {
     for (int ri = 0; ri < 32; ++ri) {
@@ -646,13 +663,11 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
 // (4096, 16, 64) = 273,152 B).  Host code never uses this name as an address: hipGetSymbolAddress, per device.
 #define DA_EDGE_IN_STATIC_MAX_B 4096
 static __device__ __align__(256) uint8_t g_edge_in_scratch[288 * 1024];
-static inline size_t in_table_offset(int B) { return ((size_t)2 * B + 255) / 256 * 256; }
-static inline size_t in_hist_offset(int B, int de_in, int de) { return (in_table_offset(B) + (size_t)(de_in + 2) * de * 2 + 255) / 256 * 256; }
 static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > EXP_IOGRID_CAP ? EXP_IOGRID_CAP : g); }
 
 template <int DE, int HE>
 static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s,
-                     uint8_t* sym_flags = nullptr) {
+                     uint8_t* sym_flags = nullptr, uint8_t* cls_map = nullptr) {
   using C = EdgeIoCfg<DE, HE>;
   if (sym_flags) {                                    // scratch: [B] symmetric, [B] one-hot, 16-byte aligned table
     if (hipMemsetAsync(sym_flags, 1, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
@@ -662,7 +677,10 @@ static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void
     if (hipMemsetAsync(hist, 0, (size_t)B * IN_HIST * sizeof(int), s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     if (de_in <= 8) {
       k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T);
-      k_edge_in_tiles<DE><<<dim3(nt * (nt + 1) / 2, B), 256, 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float), s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist);
+      const dim3 grid(nt * (nt + 1) / 2, B);
+      const size_t lds = 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float);
+      if (cls_map) k_edge_in_tiles<DE, true><<<grid, 256, lds, s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist, cls_map);
+      else k_edge_in_tiles<DE, false><<<grid, 256, lds, s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist, nullptr);
     } else if (hipMemsetAsync(sym_flags, 0, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
   }
   k_edge_in<DE, HE><<<io_grid(B * n), 256, C::IN_BYTES, s>>>(E_in, de_in, nm, (const uint4*)blob, (bf16_t*)E_out, B, n, sym_flags);
@@ -698,6 +716,24 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
   else if (de == 32 && he == 32) launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream);
   else { da_set_error("da_edge_in: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_in");
+  return DA_OK;
+}
+
+// da_edge_in_sym for a caller whose first edge layer is da_edge_layer_table: graphs that are symmetric and one-hot get one byte per
+// pair in cls_map (B,n,n) -- the row of the table in `scratch` that holds the pair's hidden features -- and their part of E_h is
+// NOT written; the other graphs (flags cleared in `scratch`) get their hidden rows in E_h as da_edge_in writes them.
+// de_in <= 8 (the table path); scratch: da_edge_in_scratch_bytes(B, de_in, de) bytes.
+int da_edge_in_classes(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                       uint8_t* scratch, int B, int n, int de, int he, void* stream) {
+  DA_CHECK_ARG(de_in >= 1 && de_in <= 8, "da_edge_in_classes: input edge feature width %d not in 1..8", de_in);
+  DA_CHECK_ARG(scratch != nullptr && cls_map != nullptr, "da_edge_in_classes: scratch / cls_map is null");
+  if (B == 0 || n == 0) return DA_OK;
+  int rc;
+  if (de == 64 && he == 128) rc = launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map);
+  else if (de == 32 && he == 32) rc = launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map);
+  else { da_set_error("da_edge_in_classes: dims (de=%d, hidden=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
+  if (rc) return rc;
+  DA_CHECK_LAUNCH("da_edge_in_classes");
   return DA_OK;
 }
 

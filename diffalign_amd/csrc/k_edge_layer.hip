@@ -13,6 +13,7 @@
 // newE^T (channels in registers, pair on the lane) -> LN1 -> FFN chained through accumulators -> LN2 -> store.
 // No LDS traffic for activations, no barriers in the main loop.
 #include "mfma_util.h"
+#include "edge_in_layout.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -90,6 +91,9 @@ struct EdgeLayerArgs {
   float* stats;           // Etoy statistics partials of E_in, k_e_stats' layout [B][stats_nchunk][4][DE], or null
   int stats_nchunk;
   int* ticket;            // work counter of the statistics tail (zero on entry)
+  // table input (first layer, TAB instantiation): the input rows of graphs with tab_flags[b] && tab_flags[B + b] are not read from
+  // E_in but taken from tab[cls[b][i][j]] (the input stage's (tab_rows x DE) bf16 table, da_edge_in_classes); other graphs: E_in
+  const uint8_t* cls; const uint4* tab; const uint8_t* tab_flags; int tab_rows;
 };
 
 // One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
@@ -302,7 +306,7 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
   sm_m = mnew;
 }
 
-template <int DE, int DX, int DFF, int NTHREADS>
+template <int DE, int DX, int DFF, int NTHREADS, bool TAB = false>
 __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   using C = EdgeCfg<DE, DX, DFF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,6 +323,11 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
   unsigned* sB1 = reinterpret_cast<unsigned*>(smem + C::BLOB_BYTES);          // [NCB][64] e_mul bias as a B-operand dword
   float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES + C::NCB * 256) + (threadIdx.x >> 6) * (2 * DX + DE);
+  const uint4* sTab = reinterpret_cast<const uint4*>(smem + C::BLOB_BYTES + C::NCB * 256 + (NTHREADS / 64) * (2 * DX + DE) * 4);   // [tab_rows][DE / 8]
+  if (TAB) {
+    uint4* wt = const_cast<uint4*>(sTab);
+    for (int t = threadIdx.x; t < a.tab_rows * (DE / 8); t += NTHREADS) wt[t] = a.tab[t];
+  }
   // bias operand of the extra GEMM1 k-step: lanes 0-31 hold (hi, lo) bf16 split of bm1[32cb + r] at k = 0, 1; lanes 32-63 zero
   for (int t = threadIdx.x; t < C::NCB * 64; t += NTHREADS) {
     const int l = t & 63, cbb = t >> 6;
@@ -405,10 +414,21 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
     // residual of block jt has consumed it (the FFN hides the HBM latency), the K (V) words of the next channel block
     // replace the current ones as soon as they are dead, and the key-mask byte is fetched one tile ahead.
     uint4 eraw[C::KS1];
+    // TAB: this graph's input rows come from the LDS table, addressed by one class byte per pair (fetched one tile ahead like the mask)
+    const bool tabrow = TAB && a.tab_flags[b] && a.tab_flags[a.B + b];     // wave-uniform
+    const uint8_t* crow = TAB ? a.cls + (size_t)row * n : nullptr;
+    unsigned ecls = 0;
     {
       const int j0c = min(jt0 * 32 + r, n - 1);
+      if (tabrow) {
+        const unsigned c0 = crow[j0c];
 #pragma unroll
-      for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
+        for (int u = 0; u < C::KS1; ++u) eraw[u] = sTab[c0 * (DE / 8) + 2 * u + h];
+        ecls = crow[min(j0c + 32, n - 1)];
+      } else {
+#pragma unroll
+        for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)j0c * DE + 16 * u + 8 * h);
+      }
     }
     const uint4* kvrow = a.KV + ((size_t)b * NT * C::NCB) * 4 * 64 + lane;
     uint4 kvA[4];
@@ -514,8 +534,14 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       {
         const int jn = min(jl + 32, n - 1);             // next tile of this row (clamped; unused after the last tile)
 #ifndef EXP_NOELOAD
+        if (tabrow) {
 #pragma unroll
-        for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
+          for (int u = 0; u < C::KS1; ++u) eraw[u] = sTab[ecls * (DE / 8) + 2 * u + h];
+          ecls = crow[min(jl + 64, n - 1)];             // class byte of the tile after the next
+        } else {
+#pragma unroll
+          for (int u = 0; u < C::KS1; ++u) eraw[u] = *reinterpret_cast<const uint4*>(Erow + (size_t)jn * DE + 16 * u + 8 * h);
+        }
 #endif
       }
       const float mean1 = xhalf_sum(sum) * (1.f / DE);
@@ -745,19 +771,20 @@ __global__ void k_kv_pack(const float* K, const float* V, int ldkv, uint4* out, 
 }
 
 // ===================================================================================================
-template <int DE, int DX, int DFF, int NT_>
+template <int DE, int DX, int DFF, int NT_, bool TAB = false>
 static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
   using C = EdgeCfg<DE, DX, DFF>;
-  auto kern = k_edge_layer<DE, DX, DFF, NT_>;
+  auto kern = k_edge_layer<DE, DX, DFF, NT_, TAB>;
+  constexpr size_t TAB_BYTES = TAB ? (size_t)18 * DE * 2 : 0;       // up to 18 table rows (de_in <= 16)
   static std::atomic<bool> attr_set[DA_MAX_DEVICES];     // the attribute is per device (and per template instance)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("edge layer: no current HIP device"); return DA_ERR_HIP; }
   if (!attr_set[dev].load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set[dev].store(true, std::memory_order_release);
   }
-  kern<<<grid_blocks, NT_, C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4, s>>>(a);
+  kern<<<grid_blocks, NT_, C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES, s>>>(a);
   return DA_OK;
 }
 // Tuning knobs of the launch (-1 = choose automatically).  Read from the environment once (DA_EDGE_THREADS, DA_EDGE_SKEW,
@@ -779,6 +806,10 @@ static EdgeTuning& edge_tuning() {
 static int edge_threads() { return edge_tuning().threads; }
 template <int DE, int DX, int DFF>
 static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
+  if (a.cls != nullptr) {
+    if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512, true>(a, grid_blocks, s);
+    return launch_edge_nt<DE, DX, DFF, 256, true>(a, grid_blocks, s);
+  }
   if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
   return launch_edge_nt<DE, DX, DFF, 256>(a, grid_blocks, s);
 }
@@ -838,7 +869,8 @@ long long da_edge_split_scratch_bytes(int B, int n, int dx) {
 static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                            const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                            const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
-                           long long split_scratch_bytes, float* stats, int stats_nchunk, int* ticket, void* stream) {
+                           long long split_scratch_bytes, float* stats, int stats_nchunk, int* ticket, void* stream,
+                           const uint8_t* cls = nullptr, const uint8_t* in_scratch = nullptr, int de_in = 0) {
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   if (B == 0 || n == 0) return DA_OK;
@@ -852,7 +884,8 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
-                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, 1, stats, stats_nchunk, ticket};
+                  newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, 1, stats, stats_nchunk, ticket,
+                  cls, cls ? reinterpret_cast<const uint4*>(in_scratch + in_table_offset(B)) : nullptr, in_scratch, de_in + 2};
   { const EdgeTuning tune = edge_tuning();
     a.stagger = tune.stagger; a.prio = tune.prio; a.skip_dead = tune.skip_dead;
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
@@ -904,6 +937,19 @@ int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, 
   DA_CHECK_ARG(stats_partials != nullptr && ticket != nullptr && stats_nchunk >= 1, "da_edge_layer_stats: statistics buffers are null");
   return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
                          split_scratch, split_scratch_bytes, stats_partials, stats_nchunk, ticket, stream);
+}
+
+// da_edge_layer for the FIRST layer behind da_edge_in_classes: the hidden input rows of the graphs that took the table path come
+// from the table in `in_scratch` through cls_map (one byte per pair) instead of E_in -- 737 MB of the benchmark batch that the input
+// stage no longer writes and this layer no longer reads; the other graphs (flags cleared) read E_in as usual.  Same bits as
+// da_edge_layer on the hidden tensor da_edge_in_sym would have written.
+int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                        const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                        const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                        long long split_scratch_bytes, const uint8_t* cls_map, const uint8_t* in_scratch, int de_in, void* stream) {
+  DA_CHECK_ARG(cls_map != nullptr && in_scratch != nullptr && de_in >= 1 && de_in <= 8, "da_edge_layer_table: class map / scratch / width");
+  return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
+                         split_scratch, split_scratch_bytes, nullptr, 0, nullptr, stream, cls_map, in_scratch, de_in);
 }
 
 }  // extern "C"

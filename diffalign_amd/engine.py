@@ -18,6 +18,7 @@ N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics t
 STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
 Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
 FUSED_X_IN = os.environ.get('DA_FUSED_X_IN', '1') != '0'   # node input stage as one kernel (da_x_in) instead of two da_linear + da_x_in_finish
+TABLE_IN = os.environ.get('DA_TABLE_IN', '1') != '0'       # first edge layer reads its input from the input stage's table (da_edge_in_classes / da_edge_layer_table)
 EARLY_QKV0 = os.environ.get('DA_EARLY_QKV0', '1') != '0'   # layer 0's q/k/v and Xtoy term behind the node input path (A/B switch)
 FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
 EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
@@ -161,8 +162,9 @@ def _qkv_buffers(pm: PackedModel, B, n, dev):
     return torch.empty(B * n, pm.dx if pm.fused_qkv else 3 * pm.dx, device=dev), kvf
 
 
-def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None):
-    """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out."""
+def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None):
+    """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out.
+    `table` = (cls_map, scratch) of da_edge_in_classes: the first layer reads its input rows from the input stage's table."""
     dev, dx, de, lib, S = E_bf16.device, pm.dx, pm.de, L.lib(), L.stream()
     ye2p1, ebias, yx1, yx2p1 = film
     E_out = torch.empty_like(E_bf16)
@@ -176,7 +178,10 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
             L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
             C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
             L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
-    if stats_out is not None:
+    if table is not None:
+        assert stats_out is None
+        L.check(lib.da_edge_layer_table(*args, L.ptr(table[0]), L.ptr(table[1]), _i(pm.de_in), S), 'da_edge_layer_table')
+    elif stats_out is not None:
         L.check(lib.da_edge_layer_stats(*args, L.ptr(stats_out), _i(stats_out.shape[1]), L.ptr(ticket), S), 'da_edge_layer_stats')
     else:
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
@@ -289,7 +294,7 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre=None):
+def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre=None, table0=None):
     """The layer stack with three streams.  Between two edge kernels two chains run: the y branch (y_update(l) needs the Etoy
     statistics the edge kernel of layer l leaves, then the FiLM vectors of layer l+1: ~100 us, 64 small workgroups) and the node chain
     (merge, node tail of layer l, q/k/v of layer l+1: ~80 us).  The LONGER one, the y branch, stays on the caller's stream right
@@ -330,7 +335,7 @@ def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n,
         xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
         if ev_x is not None:
             main.wait_event(ev_x)
-        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail)
+        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None)
         ev_edge = main.record_event()
         with torch.cuda.stream(side):                # node chain
             side.wait_event(ev_edge)
@@ -426,8 +431,17 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             align_done = side2.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
     sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
-    L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
-                               _i(pm.he), S), 'da_edge_in_sym')
+    # one-hot symmetric inputs (every diffusion state): the first layer takes its input rows from the input stage's table through a
+    # one-byte class per pair, and the hidden tensor is neither written here nor read there
+    table0 = None
+    if TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None and Y_ON_MAIN:
+        cls_map = torch.empty(B, n, n, dtype=torch.uint8, device=dev)
+        L.check(lib.da_edge_in_classes(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags), _i(B),
+                                       _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_in_classes')
+        table0 = (cls_map, sym_flags)
+    else:
+        L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
+                                   _i(pm.he), S), 'da_edge_in_sym')
     yh = torch.empty(B, pm.dy, device=dev)
     film0 = film_buffers(pm, B, dev) if side is not None else None
     y_done0 = None
@@ -453,7 +467,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
         if Y_ON_MAIN:
-            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre=pre)
+            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre=pre, table0=table0)
         else:
             # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
             film, y_done = film0, y_done0

@@ -291,6 +291,18 @@ int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, 
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                         long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, void* stream);
+
+/* First layer without a materialised hidden input (round 2).  da_edge_in_classes = da_edge_in_sym that writes, for the graphs
+ * that are symmetric and one-hot (every diffusion state), one byte per pair -- the row of the table in `scratch` holding
+ * mlp_in_E of that pair (transformer_model_with_y.py:657-662) -- into cls_map (B,n,n) instead of their hidden rows in E_h; the
+ * other graphs get their E_h rows as da_edge_in writes them.  da_edge_layer_table = da_edge_layer whose input rows of the
+ * table-path graphs come from that table (in_scratch = the same scratch) instead of E_h.  de_in <= 8. */
+int da_edge_in_classes(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                       uint8_t* scratch, int B, int n, int de, int he, void* stream);
+int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
+                        const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
+                        const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
+                        long long split_scratch_bytes, const uint8_t* cls_map, const uint8_t* in_scratch, int de_in, void* stream);
 /* Launch tuning of da_edge_layer / da_edge_layer_stats, process-wide (no counterpart in the reference; for tests and A/B timing):
  * threads per workgroup 256 | 512 (0 = keep), skew = whole rows the older wave of every SIMD pair takes more than the younger one,
  * tail_old = the split rows' runs go to the older waves only (both: -1 = chosen from the problem size), stagger, prio = start

@@ -324,3 +324,32 @@ def test_x_in_refuses_unbuilt_widths():
     x = torch.zeros(32, 37, device=D); m = torch.ones(32, dtype=torch.uint8, device=D); o = torch.zeros(32, 96, device=D)
     rc = L.lib().da_x_in(L.ptr(x), C.c_int(37), L.ptr(m), L.ptr(None), L.ptr(x), L.ptr(o), C.c_int(32), C.c_int(96), C.c_int(96), L.stream())
     assert rc != 0 and 'not built' in L.last_error()
+
+
+@pytest.mark.parametrize('dims,L_,B,n,P', [(FULL, 2, 3, 70, None), (TINY, 2, 4, 33, 5), (FULL, 1, 9, 300, 142)], ids=['full_n70', 'tiny_n33', 'full_n300_split_rows'])
+def test_first_layer_from_table_equals_materialised_input(dims, L_, B, n, P):
+    """da_edge_in_classes + da_edge_layer_table (the first layer takes its input rows from the input stage's table through one class byte
+    per pair; the hidden tensor is neither written nor read for graphs that are symmetric and one-hot) against da_edge_in_sym +
+    da_edge_layer: the same logits bit for bit -- also when one graph of the batch is NOT one-hot and one is not symmetric (those
+    read their materialised rows), and with padded graphs / partial tiles / split rows."""
+    from diffalign_amd import engine
+    m, sd = build(dims, L_, seed=23)
+    hd = dims['hidden_dims']
+    X, E, y, nm, am, pos, mol = inputs(B, n, seed=37, P=P, dx=hd['dx'])
+    E = E.clone()
+    E[1, 2, 3] = 0.5 * (E[1, 2, 3] + E[1, 2, 3].roll(1)); E[1, 3, 2] = E[1, 2, 3]        # graph 1: symmetric, not one-hot
+    if B > 2:
+        E[2, 4, 5] = E[2, 4, 5].roll(1)                                                    # graph 2: one-hot, not symmetric
+    args = [t.to(D) for t in (X, E, y, nm, am, pos, mol)]
+    outs = {}
+    for flag in (True, False):
+        engine.TABLE_IN = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = m(*args)
+        finally:
+            engine.TABLE_IN = True
+    for a_, b_ in zip(outs[True][:3], outs[False][:3]):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_)
+    o = O.denoiser_forward(sd, X, E, y, nm, L_, hd['n_head'], (KX, KE, 1), am, pos, mol, True)
+    assert rel_l2(outs[True][1], o[1]) <= 2e-2 and rel_l2(outs[True][0], o[0]) <= 2e-2
