@@ -303,10 +303,15 @@ def main():
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02', 'edge_layer_traffic.json')) as f:
             tj = json.load(f)
         if tj['workload'] == {'B': B, 'n': n} and args.workload == 'full':
-            traffic = tj['hbm_bytes_per_launch']
-            if engine.STATS_TAIL and 'with_stats_tail' in tj:   # layers >= 1 run the kernel with its statistics tail
+            # mean over the step's launches: the first layer (bare kernel, or the table-input instantiation that reads no hidden
+            # input) and the layers >= 1 that run the kernel with its statistics tail
+            first = tj['hbm_bytes_per_launch']
+            if engine.TABLE_IN and 'table_input_first_layer' in tj:
+                first = tj['table_input_first_layer']['hbm_bytes_per_launch']
+            traffic = first
+            if engine.STATS_TAIL and 'with_stats_tail' in tj:
                 nl = len(model.model.tf_layers)
-                traffic = (traffic + (nl - 1) * tj['with_stats_tail']['hbm_bytes_per_launch']) / nl
+                traffic = (first + (nl - 1) * tj['with_stats_tail']['hbm_bytes_per_launch']) / nl
     except (OSError, KeyError, ValueError):
         pass
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
