@@ -229,6 +229,10 @@ def main():
     masks = graph.get_node_masks(data, model.dataset_info.atom_decoder, model.dataset_info.bond_decoder, 'product_and_sn',
                                  'product_and_sn')
     tm = model.transition_model_eval
+    if args.extra_features == 'device':
+        # as sample_one_batch: the fixed side's share of the features' eigensolver is kept along the chain (DA_EIG_CACHE=0: off)
+        from diffalign_amd.extra_features import EigCache
+        z_t.eig_cache = EigCache.from_free_masks(masks[1], data.node_mask)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     state = {'t': 50}
 

@@ -121,7 +121,9 @@ __device__ void tri_solve(const double* d, const double* e, int n, double lam, d
 __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restrict__ Lmat, const uint8_t* __restrict__ node_mask,
                                                                  const float* __restrict__ pad_noise, float* __restrict__ n_comp,
                                                                  float* __restrict__ ev5, float* __restrict__ nonlcc,
-                                                                 float* __restrict__ vec2, double* __restrict__ evals_out, int n) {
+                                                                 float* __restrict__ vec2, double* __restrict__ evals_out, int n,
+                                                                 const int* __restrict__ fixed_from, int* __restrict__ cache_state,
+                                                                 double* __restrict__ cache, int mmax) {
   extern __shared__ double sm[];
   double* s_u = sm;                 // n   Householder vector of the current step
   double* s_p = sm + n;             // n
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   double* s_red = sm + 17 * n;      // 32
   double* s_lam = s_red + 32;       // 8
   double* s_pp = s_lam + 8;         // EIG_THREADS  partial sums of A u per (row class, column): summed in a fixed order
-  __shared__ int s_ncomp, s_nreal, s_best;
+  __shared__ int s_ncomp, s_nreal, s_best, s_coupled;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NWV = EIG_THREADS / 64;
   double* A = Lmat + (size_t)b * n * n;
@@ -150,7 +152,28 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   double* s_part = s_red;          // [2][16] per-wave partials, double buffered
   int* s_iu = reinterpret_cast<int*>(s_w);             // [n] compacted index list
   int* s_wc = reinterpret_cast<int*>(s_w + n);         // [16] per-wave counts of the compaction
-  for (int k = n - 1; k >= 1; --k) {
+  // Fixed trailing block (da_extra_eigen_solve_cached): the nodes p0 .. n-1 keep all their edges from call to call (the product
+  // side of a reaction along a reverse chain, graph.apply_mask) and share no edge with the nodes before them.  Rows k >= p0 are
+  // reduced first (k runs downwards) and their reflectors never leave the block, so what those steps leave behind -- the rows'
+  // lower triangles with the updated diagonal, e_k and h_k -- is the same bits at every call: kept per graph after the first
+  // call (state 0 -> 1) and copied back afterwards, and the reduction starts at row p0.  A block that does share an edge with
+  // the rest is noticed while it is reduced (state -1: always reduced in full).
+  const int p0 = cache ? min(max(fixed_from[b], 0), n) : n;
+  const int cstate = (cache && p0 < n && n - p0 <= mmax) ? cache_state[b] : -1;
+  double* cA = cache ? cache + (size_t)b * (mmax + 2) * mmax : nullptr;       // [mmax][mmax] rows, then e, then h
+  int kstart = n - 1;
+  if (tid == 0) s_coupled = 0;
+  if (cstate == 1) {
+    const int mm = n - p0;
+    for (int t = tid; t < mm * mm; t += EIG_THREADS) {
+      const int rk = t / mm, cj = t - rk * mm;
+      if (cj <= rk) A[(size_t)(p0 + rk) * n + p0 + cj] = cA[(size_t)rk * mmax + cj];
+    }
+    for (int t = tid; t < mm; t += EIG_THREADS) { s_e[p0 + t] = cA[(size_t)mmax * mmax + t]; s_h[p0 + t] = cA[(size_t)(mmax + 1) * mmax + t]; }
+    kstart = p0;                                        // row p0 itself has nothing before it: the loop sets e = 0, h = 0 for it
+    __syncthreads();
+  }
+  for (int k = kstart; k >= 1; --k) {
     double part = 0.0;
     for (int j = tid; j < k; j += EIG_THREADS) { const double x = A[(size_t)k * n + j]; s_u[j] = x; s_p[j] = 0.0; if (j < k - 1) part += x * x; }
     part = wsum(part);
@@ -175,6 +198,7 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
     // reactant fragments, isolated atoms), everything outside is exactly zero and is skipped: U = {j: u_j != 0} bounds the
     // rows of the product A u, T = {j: u_j != 0 or (A u)_j != 0} the rank-2 update.  Ordered compaction (deterministic sums).
     const int nU = compact(s_iu, s_wc, k, [&](int j) { return s_u[j] != 0.0; });
+    if (cstate == 0 && k >= p0 && tid == 0 && s_iu[0] < p0) s_coupled = 1;   // the block reaches outside itself: not cacheable
     // h p = A u.  A is symmetric: (A u)_j = sum_{i in U} A[i][j] u_i, one thread per column j and row class, the rows walked
     // with 16 independent loads in flight; coalesced in j; partial sums meet in s_pp[row class][column]
     const int CW = (k + 63) & ~63;                      // columns rounded up to whole waves
@@ -242,6 +266,19 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
 #ifdef EXP_EIG_STAMP
   const long long st1 = __builtin_readcyclecounter();
 #endif
+  if (cstate == 0) {                                    // first call: keep what the block's steps left (nothing later touched it)
+    const int mm = n - p0;
+    if (!s_coupled) {
+      for (int t = tid; t < mm * mm; t += EIG_THREADS) {
+        const int rk = t / mm, cj = t - rk * mm;
+        if (cj <= rk) cA[(size_t)rk * mmax + cj] = A[(size_t)(p0 + rk) * n + p0 + cj];
+      }
+      for (int t = tid; t < mm; t += EIG_THREADS) {
+        cA[(size_t)mmax * mmax + t] = p0 + t >= 1 ? s_e[p0 + t] : 0.0; cA[(size_t)(mmax + 1) * mmax + t] = p0 + t >= 1 ? s_h[p0 + t] : 0.0;
+      }
+    }
+    if (tid == 0) cache_state[b] = s_coupled ? -1 : 1;
+  }
   for (int i = tid; i < n; i += EIG_THREADS) s_d[i] = A[(size_t)i * n + i];
   if (tid == 0) { s_e[0] = 0.0; s_h[0] = 0.0; s_nreal = 0; }
   __syncthreads();
@@ -418,9 +455,12 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
 extern "C" {
 
 /* see include/diffalign_hip.h */
-int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
-                         float* vec2, double* evals6 /*may be NULL*/, int B, int n, void* stream) {
+int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
+                                float* vec2, double* evals6 /*may be NULL*/, int B, int n, const int* fixed_from, int* cache_state,
+                                double* cache, int mmax, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 1 && n <= 1024, "da_extra_eigen_solve: n = %d outside 1..1024 (LDS work arrays)", n);
+  DA_CHECK_ARG(cache == nullptr || (fixed_from != nullptr && cache_state != nullptr && mmax >= 1 && mmax <= n),
+               "da_extra_eigen_solve_cached: cache given without fixed_from / cache_state, or mmax = %d outside 1..n", mmax);
   if (B == 0) return DA_OK;
   const size_t lds = ((size_t)17 * n + 32 + 8 + EIG_THREADS) * sizeof(double);
   static std::atomic<bool> attr_set[DA_MAX_DEVICES];     // the attribute is per device
@@ -432,9 +472,15 @@ int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_n
     attr_set[dev].store(true, std::memory_order_release);
   }
   DA_CHECK_ARG(lds <= 160 * 1024 - 64, "da_extra_eigen_solve: n = %d needs %zu B of LDS", n, lds);
-  k_extra_eig_solve<<<B, EIG_THREADS, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n);
+  k_extra_eig_solve<<<B, EIG_THREADS, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
+                                                                  fixed_from, cache_state, cache, mmax);
   DA_CHECK_LAUNCH("da_extra_eigen_solve");
   return DA_OK;
+}
+
+int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
+                         float* vec2, double* evals6 /*may be NULL*/, int B, int n, void* stream) {
+  return da_extra_eigen_solve_cached(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, B, n, nullptr, nullptr, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -125,8 +125,10 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
             from . import extra_features as XF
             if self._extra_calc is None:
                 self._extra_calc = (XF.ExtraFeatures('all', self.dataset_info), XF.ExtraMolecularFeatures(self.dataset_info))
+            # `eig_cache`: set on the chain's state object by sample_one_batch (the fixed product block's part of the eigensolver
+            # is kept along the chain); objects derived from it (get_new_object) do not carry it
             X_extra, y_extra = XF.compute_extra_features(noisy_data.X, noisy_data.E, noisy_data.node_mask, *self._extra_calc,
-                                                         pad_noise=pad_noise)
+                                                         pad_noise=pad_noise, eig_cache=getattr(noisy_data, 'eig_cache', None))
         # a view of noisy_data with widened X and y: the reference's get_new_object clones every field (E: 161 MB at the
         # benchmark size, 60 us per step) for an object that only feeds the denoiser
         return PlaceHolder(X=torch.cat((noisy_data.X, X_extra), -1), E=noisy_data.E, y=torch.cat((noisy_data.y, y_extra), -1),

@@ -50,9 +50,37 @@ def _cycles(A: torch.Tensor, nm_u8: torch.Tensor):
 # 'hip' (default): the one-launch batched partial eigensolver of csrc/k_extra_eig.hip; 'torch': torch.linalg.eigh (rocSOLVER
 # syevd, fp64, the reference's routine) followed by k_extra_eigen -- 3.5x slower at B = 64, n = 300, kept for cross-checks.
 EIGENSOLVER = os.environ.get('DA_EXTRA_EIGH', 'hip')
+EIG_CACHE = os.environ.get('DA_EIG_CACHE', '1') != '0'        # A/B switch: the fixed block's reflectors kept along a chain (EigCache)
 
 
-def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Tensor], solver: Optional[str] = None):
+class EigCache:
+    """What the eigensolver may keep between calls on the SAME sequence of graphs (a reverse chain): the nodes from
+    `fixed_from[b]` on keep all their edges at every step (graph.apply_mask: every pair with a fixed endpoint stays at the
+    condition's value) -- the product side of a reaction, roughly half of the matrix and, with absorbing noise, most of its
+    connected part.  The first call tridiagonalises everything and keeps that block's reflectors; later calls reduce only the
+    rows before it (da_extra_eigen_solve_cached: same bits as the uncached solver).  One object per sample_one_batch call."""
+
+    def __init__(self, fixed_from: torch.Tensor, n: int):
+        B = fixed_from.shape[0]
+        dev = fixed_from.device
+        self.n = n
+        self.fixed_from = fixed_from.to(torch.int32).clamp(0, n).contiguous()
+        self.mmax = int(n - int(self.fixed_from.min())) if B else 0          # one host sync per chain, before its first step
+        self.state = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.store = torch.empty(B, self.mmax + 2, self.mmax, dtype=torch.float64, device=dev) if self.mmax > 0 else None
+
+    @staticmethod
+    def from_free_masks(free_e: torch.Tensor, node_mask: torch.Tensor) -> 'EigCache':
+        """free_e (B,n): 1 where the node's edges may change (graph.get_node_masks); padding never changes.  The fixed block starts
+        behind the last node that is real and free."""
+        B, n = node_mask.shape
+        moving = (free_e != 0) & (node_mask != 0)
+        idx = torch.arange(1, n + 1, device=node_mask.device)[None, :].expand(B, n)
+        return EigCache(torch.where(moving, idx, torch.zeros_like(idx)).amax(dim=1), n)
+
+
+def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Tensor], solver: Optional[str] = None,
+           cache: Optional[EigCache] = None):
     """Eigen-features of the fp64 Laplacians (B,n,n) (extra_features.py:117-128, :158-204).  `Lap` is overwritten."""
     B, n, _ = Lap.shape
     dev = Lap.device
@@ -62,6 +90,14 @@ def _eigen(Lap: torch.Tensor, nm_u8: torch.Tensor, pad_noise: Optional[torch.Ten
     ncomp = torch.empty(B, device=dev); ev5 = torch.empty(B, 5, device=dev)
     nonlcc = torch.empty(B, n, device=dev); vec2 = torch.empty(B, n, 2, device=dev)
     if (solver or EIGENSOLVER) == 'hip' and n <= 1024:
+        if cache is not None and cache.store is not None and EIG_CACHE:
+            assert cache.n == n and cache.state.shape[0] == B and cache.state.device == dev, 'EigCache belongs to another batch'
+            L.check(L.lib().da_extra_eigen_solve_cached(L.ptr(Lap, torch.float64), L.ptr(nm_u8), L.ptr(pad_noise, torch.float32), L.ptr(ncomp),
+                                                        L.ptr(ev5), L.ptr(nonlcc), L.ptr(vec2), C.c_void_p(0), _i(B), _i(n),
+                                                        L.ptr(cache.fixed_from, torch.int32), L.ptr(cache.state, torch.int32),
+                                                        L.ptr(cache.store, torch.float64), _i(cache.mmax), L.stream()),
+                    'da_extra_eigen_solve_cached')
+            return ncomp, ev5, nonlcc, vec2
         L.check(L.lib().da_extra_eigen_solve(L.ptr(Lap, torch.float64), L.ptr(nm_u8), L.ptr(pad_noise, torch.float32), L.ptr(ncomp), L.ptr(ev5),
                                              L.ptr(nonlcc), L.ptr(vec2), C.c_void_p(0), _i(B), _i(n), L.stream()), 'da_extra_eigen_solve')
         return ncomp, ev5, nonlcc, vec2
@@ -87,7 +123,8 @@ class ExtraFeatures(nn.Module):
         self.max_n_nodes = dataset_info.max_n_nodes
         self.features_type = extra_features_type
 
-    def forward(self, E, node_mask, pad_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def forward(self, E, node_mask, pad_noise: Optional[torch.Tensor] = None,
+                eig_cache: Optional[EigCache] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         B, n = node_mask.shape
         dev = E.device
         E = E.contiguous().float()
@@ -99,7 +136,7 @@ class ExtraFeatures(nn.Module):
         E_res = torch.zeros((*E.shape[:-1], 0), device=dev, dtype=E.dtype)
         if self.features_type == 'cycles':
             return x_cycles, E_res, torch.hstack((n_frac, y_cycles))
-        ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise)
+        ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise, cache=eig_cache)
         y_res = torch.hstack((n_frac, y_cycles, ncomp.unsqueeze(-1), ev5))
         if self.features_type == 'eigenvalues':
             return x_cycles, E_res, y_res
@@ -143,7 +180,7 @@ class ExtraMolecularFeatures(nn.Module):
 
 
 def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: ExtraMolecularFeatures,
-                           pad_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           pad_noise: Optional[torch.Tensor] = None, eig_cache: Optional[EigCache] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The two calculators of diffusion_abstract.py:350-372 with ONE pass over the edge state.
     Returns (X_extra (B,n,8), y_extra (B,12)) in the reference's concatenation order (features_type 'all')."""
     assert extra.features_type == 'all'
@@ -152,7 +189,7 @@ def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: Ext
     nm_u8 = L.as_u8(node_mask)
     A, Lap, vw, vp = _adjacency(E, nm_u8, molecular.consts(dev)[1], True)
     x_cycles, y_cycles = _cycles(A, nm_u8)
-    ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise)
+    ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise, cache=eig_cache)
     cv, w = molecular.from_valency_sums(X, vw, vp)
     n_frac = node_mask.sum(dim=1, keepdim=True).float() / extra.max_n_nodes
     X_extra = torch.cat((x_cycles, nonlcc.unsqueeze(-1), vec2, cv), dim=-1)

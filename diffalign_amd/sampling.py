@@ -71,6 +71,12 @@ class SamplingMixin:
             return z
 
         z_t = fix(z_t)
+        # the condition's side of the graph keeps its edges at every step: its share of the extra features' eigensolver (the
+        # larger share: with absorbing noise the free side is mostly isolated atoms) is done once per chain (extra_features.EigCache)
+        eig_cache = None
+        if self.cfg.neuralnet.extra_features and self.extra_features_fn is None and self.cfg.diffusion.denoiser == 'neuralnet':
+            from .extra_features import EigCache
+            eig_cache = EigCache.from_free_masks(masks[1], node_mask)
         T_eval = self.cfg.diffusion.diffusion_steps_eval
         assert self.T % T_eval == 0, 'diffusion_steps_eval should be divisible by diffusion_steps'
         eval_step_size = self.T // T_eval
@@ -87,6 +93,7 @@ class SamplingMixin:
         all_y = all_t.float() * eval_step_size
         for t_int in range(T_eval, 0, -1):
             t_array = all_t[t_int]
+            z_t.eig_cache = eig_cache                                      # read by compute_extra_data; not carried by get_new_object
             z_t.y = all_y[t_int]                                           # raw train-scale step index (sampling.py:76)
             s_int = t_int - 1
             record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)

@@ -406,6 +406,18 @@ int da_extra_eigen(const double* evals, const double* evecs, long long ld_row, l
 int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
                          float* vec2, double* evals6, int B, int n, void* stream);
 
+/* da_extra_eigen_solve for a caller that evaluates the same graphs again and again with a trailing block of nodes whose edges
+ * never change -- the product side of a reaction along a reverse chain (sampling.py:76-178 calls the extra features at every
+ * step; utils/graph.py:411-470 apply_mask keeps every edge with a fixed endpoint).  fixed_from (B) int32: first node of graph
+ * b's fixed block (n: none).  cache (B, mmax + 2, mmax) fp64 and cache_state (B) int32, zero before the first call, belong to
+ * the caller and to THIS sequence of graphs: the first call reduces everything and keeps the block's reflectors (state 1, or -1
+ * when the block shares an edge with the nodes before it), later calls copy them back and reduce only the rows before the block.
+ * Same bits as da_extra_eigen_solve as long as the block really is unchanged (the caller's promise; not checked).
+ * cache == NULL: da_extra_eigen_solve.  Blocks larger than mmax are reduced in full every time. */
+int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5,
+                                float* nonlcc, float* vec2, double* evals6, int B, int n, const int* fixed_from, int* cache_state,
+                                double* cache, int mmax, void* stream);
+
 /* charge = argmax_c(X_c * valencies_c) - val_weighted, valency = val_plain, weight = sum_i atom_weights[argmax X_i] /
  * max_weight (extra_features_molecular.py:29-72; the argmax INDEX is used, as in the reference). */
 int da_extra_molecular(const float* X, const float* valencies, const float* atom_weights, const float* val_weighted,

@@ -184,3 +184,42 @@ def test_extra_features_tiny_graphs_vs_oracle(n, reals):
         assert (Xe.cpu()[..., 3:6][~nm] == 0).all()
     Xe, ye = XF.compute_extra_features(X[:0].to(D), E[:0].to(D), nm[:0].to(D), ef, mf)
     assert Xe.shape == (0, n, 8) and ye.shape == (0, 12)
+
+
+@pytest.mark.parametrize('n,P,B', [(300, 142, 3), (300, None, 4), (40, 10, 5)])
+def test_eigensolver_fixed_block_cache_is_bit_identical(n, P, B):
+    """da_extra_eigen_solve_cached (extra_features.EigCache): along a chain the product side and the supernode keep their edges, the
+    first call keeps that block's reflectors and the later ones reduce only the rows before it.  Every feature equals the uncached
+    solver's bit for bit at every step; a block that shares an edge with the free side is noticed (state -1) and reduced in full."""
+    from diffalign_amd import extra_features as XF, graph
+    from diffalign_amd import synthetic as S
+    from diffalign_amd.placeholder import PlaceHolder
+    info = extra_info(SimpleNamespace)
+    ef, mf = XF.ExtraFeatures('all', info), XF.ExtraMolecularFeatures(info)
+    true = S.make_reaction_batch(B, n, seed=11, P=P, kx=len(ATOMS))
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    bonds = ['none', 'SINGLE', 'DOUBLE', 'TRIPLE', 'mol', 'within', 'across']
+    masks = graph.get_node_masks(data, list(ATOMS), bonds, 'product_and_sn', 'product_and_sn')
+    cache = XF.EigCache.from_free_masks(masks[1], data.node_mask)
+    suno = true['X'].argmax(-1) == len(ATOMS) - 1
+    assert torch.equal(cache.fixed_from.cpu().long(), suno.float().argmax(-1)), 'the fixed block starts at the supernode'
+    pn = torch.randn(B, n, generator=torch.Generator().manual_seed(3)).to(D)
+    for step, t in enumerate((480, 300, 120, 10, 0)):
+        z = S.noised_state(true, t, 500, len(ATOMS) - 2, seed=20 + step)
+        X, E, nm = z['X'].to(D), z['E'].to(D), z['node_mask'].to(D)
+        want = XF.compute_extra_features(X, E, nm, ef, mf, pad_noise=pn)
+        got = XF.compute_extra_features(X, E, nm, ef, mf, pad_noise=pn, eig_cache=cache)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), f'step {step}'
+        assert bool((cache.state == 1).all())
+    # a reactant atom bonded to a product atom: the block is not closed, nothing is kept, results unchanged
+    cache2 = XF.EigCache.from_free_masks(masks[1], data.node_mask)
+    for step, t in enumerate((300, 50)):
+        z = S.noised_state(true, t, 500, len(ATOMS) - 2, seed=40 + step)
+        E = z['E'].clone()
+        last = int(true['node_mask'][0].sum()) - 1
+        E[0, 0, last] = 0.; E[0, last, 0] = 0.; E[0, 0, last, 1] = 1.; E[0, last, 0, 1] = 1.
+        X, E, nm = z['X'].to(D), E.to(D), z['node_mask'].to(D)
+        want = XF.compute_extra_features(X, E, nm, ef, mf, pad_noise=pn)
+        got = XF.compute_extra_features(X, E, nm, ef, mf, pad_noise=pn, eig_cache=cache2)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert int(cache2.state[0]) == -1 and bool((cache2.state[1:] == 1).all())
