@@ -33,6 +33,8 @@ class EMA(nn.Module):
             if packed is not None:
                 model._packed = None                                      # the packed inference weights are a cache, not state
             self.ema_model = copy.deepcopy(model)
+            if hasattr(self.ema_model, '_plist'):
+                self.ema_model._plist = None                              # likewise: rebuilt from the copy's own parameters
             if packed is not None:
                 model._packed = packed
         self.ema_model.requires_grad_(False)

@@ -35,15 +35,24 @@ class _DenoiserBase(nn.Module):
         self.mlp_out_y = mk(hidden_dims['dy'], hidden_mlp_dims['y'], output_dims['y'], False)   # unused by forward, kept for checkpoints
         self._packed = None
         self._packed_key = None
+        self._plist = None      # list(self.parameters()), dropped when the module tree is rebuilt by _apply (.to(), .float(), ...)
         self._saved = None      # dict filled by engine.model_forward for the output-stage backward (training.py)
 
     def _pack(self, device):
-        key = (str(device), L.weights_epoch) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # re-pack when any parameter was rewritten (torch's version counters), moved (storage pointers) or stepped behind torch's back
+        # (weights_epoch).  The parameter list is kept: walking the module tree costs more than the whole comparison (531 tensors).
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        key = (str(device), L.weights_epoch, [p.data_ptr() for p in self._plist], [p._version for p in self._plist])
         if self._packed is None or self._packed_key != key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._packed = engine.PackedModel(sd, device, self.n_layers, self.n_head)
             self._packed_key = key
         return self._packed
+
+    def _apply(self, fn, *a, **k):
+        self._plist = None
+        return super()._apply(fn, *a, **k)
 
     def _differentiable(self):
         """train() mode with autograd on: the fp32 training forward (train_forward.py) instead of the fused bf16 inference path."""

@@ -1,6 +1,6 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ['bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline']
+sys.argv = ['bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline'] + sys.argv[1:]
 import bench
 # monkeypatch: wrap torch.cuda.synchronize to report the host time of the timed loop
 orig_sync = torch.cuda.synchronize
