@@ -313,7 +313,7 @@ def main():
             if engine.TABLE_IN and 'table_input_first_layer' in tj:
                 first = tj['table_input_first_layer']['hbm_bytes_per_launch']
             traffic = first
-            if engine.STATS_TAIL and 'with_stats_tail' in tj:
+            if engine.use_stats_tail(n) and 'with_stats_tail' in tj:
                 nl = len(model.model.tf_layers)
                 traffic = (first + (nl - 1) * tj['with_stats_tail']['hbm_bytes_per_launch']) / nl
     except (OSError, KeyError, ValueError):
@@ -322,9 +322,9 @@ def main():
             'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
             'algorithmic_bytes_per_launch': bytes_launch, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
-    if engine.STATS_TAIL:
+    if engine.use_stats_tail(n):
         roof['note'] = ('launches of layers >= 1 include the Etoy statistics tail (da_edge_layer_stats: early-finishing waves stream '
-                        'E_in a second time, +0.74 GB and +0.06 ms per launch) that replaces a separate 0.155 ms pass; '
+                        'E_in a second time, +0.74 GB and +0.06 to +0.12 ms per launch) that replaces a separate 0.155 ms pass; '
                         'DA_STATS_TAIL=0 times the bare kernel')
     if rank == 0:
         out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',

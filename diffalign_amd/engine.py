@@ -14,8 +14,28 @@ from . import pack
 
 N_STAT_CHUNKS = 32
 N_XSTAT_CHUNKS = 8
-N_TAIL_CHUNKS = int(os.environ.get('DA_TAIL_CHUNKS', '64'))       # statistics tickets per graph in the edge kernel's tail (da_edge_layer_stats)
-STATS_TAIL = os.environ.get('DA_STATS_TAIL', '1') != '0'   # Etoy statistics of layers >= 1 from the edge kernel's tail instead of a separate pass
+# Etoy statistics of layers >= 1 from the edge kernel's tail (da_edge_layer_stats) instead of a separate pass.  A ticket of the tail is
+# one (graph, chunk of pairs): about 1,300 pairs per ticket is where the counter's round trip and the per-ticket fold stop showing
+# (64 tickets per graph at n = 300, 16 at n = 140; measured steps at B = 64, n = 140: 4.23 / 4.08 / 4.03 / 4.18 ms with 4 / 8 / 16 / 64).
+# Below n = 112 the separate pass wins (B = 100, n = 72: 2.72 ms against 2.78 with 4 tickets and 3.15 with 64), from there on the tail.
+# DA_STATS_TAIL=0 / 1 forces the separate pass / the tail at every size, DA_TAIL_CHUNKS fixes the ticket count.
+_STATS_TAIL_ENV = os.environ.get('DA_STATS_TAIL')
+STATS_TAIL = _STATS_TAIL_ENV != '0'
+STATS_TAIL_MIN_N = 0 if _STATS_TAIL_ENV == '1' else 112
+_TAIL_CHUNKS_ENV = os.environ.get('DA_TAIL_CHUNKS')
+
+
+def tail_chunks(n: int) -> int:
+    """Statistics tickets per graph of the edge kernel's tail at graph size n."""
+    if _TAIL_CHUNKS_ENV:
+        return int(_TAIL_CHUNKS_ENV)
+    return max(4, min(64, (n * n) // 1300))
+
+
+def use_stats_tail(n: int) -> bool:
+    return STATS_TAIL and n >= STATS_TAIL_MIN_N
+
+
 Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
 FUSED_X_IN = os.environ.get('DA_FUSED_X_IN', '1') != '0'   # node input stage as one kernel (da_x_in) instead of two da_linear + da_x_in_finish
 TABLE_IN = os.environ.get('DA_TABLE_IN', '1') != '0'       # first edge layer reads its input from the input stage's table (da_edge_in_classes / da_edge_layer_table)
@@ -217,7 +237,7 @@ def layer_main(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, B, n, film=None, 
     fused edge layer, the fused node tail.  X (B,n,dx) fp32, E (B,n,n,de) bf16, y (B,dy) fp32 -> X', E'.
     `film`: the FiLM vectors if the caller computed them already (layer_film); `before_edge` / `after_edge`: hooks called
     right before / after the edge kernel is enqueued (stream joins of the pipelined y branch); `stats_out`: buffer
-    (B, N_TAIL_CHUNKS, 4, de) that receives the Etoy statistics partials of E_bf16 from the edge kernel's tail."""
+    (B, tail_chunks(n), 4, de) that receives the Etoy statistics partials of E_bf16 from the edge kernel's tail."""
     film = film if film is not None else layer_film(pm, lw, y, B, film_buffers(pm, B, X.device))
     Qm, kvf = _qkv(pm, lw, X, nm_u8, B, n)
     if before_edge is not None:
@@ -261,14 +281,14 @@ def layer_y(pm: PackedModel, lw: dict, X, y, estats, B, n):
     return y_update(pm, lw, y, node_stats(pm, X, B, n), estats, B, n, torch.empty(B, pm.dy, device=X.device))
 
 
-def tail_stats_buffer(pm: PackedModel, B, dev):
-    return torch.empty(B, N_TAIL_CHUNKS, 4, pm.de, dtype=torch.float32, device=dev)
+def tail_stats_buffer(pm: PackedModel, B, n, dev):
+    return torch.empty(B, tail_chunks(n), 4, pm.de, dtype=torch.float32, device=dev)
 
 
 def layer_forward(pm: PackedModel, lw: dict, X, E_bf16, y, nm_u8, estats, B, n):
     """One XEyTransformerLayer (neuralnet/layers.py:330-361) on the current stream.  estats: Etoy statistics partials of
     E_bf16, or None: the edge kernel's tail computes them (STATS_TAIL) or a separate pass does."""
-    tail = tail_stats_buffer(pm, B, X.device) if estats is None and STATS_TAIL else None
+    tail = tail_stats_buffer(pm, B, n, X.device) if estats is None and use_stats_tail(n) else None
     if estats is None and tail is None:
         estats = edge_stats(E_bf16, B, n, pm.de)
     X2, E_out = layer_main(pm, lw, X, E_bf16, y, nm_u8, B, n, stats_out=tail)
@@ -325,7 +345,7 @@ def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n,
     keep = []
     for li, lw in enumerate(pm.layers):
         nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
-        tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
+        tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
         st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
         X_next = torch.empty(B, n, pm.dx, device=dev)
         y_next = torch.empty(B, pm.dy, device=dev)
@@ -473,7 +493,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             film, y_done = film0, y_done0
             keep = []
             for li, lw in enumerate(pm.layers):
-                tail = tail_stats_buffer(pm, B, dev) if li > 0 and STATS_TAIL else None
+                tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
                 st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
                 xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
                 xy = torch.empty(B, pm.dy, device=dev)

@@ -148,7 +148,7 @@ def test_stages_vs_oracle(dims):
     gX, gE, gy = engine.layer_forward(pm, pm.layers[0], Xh_d, Eb, yh_d, nm_d, st, B, n)
     torch.cuda.synchronize()
     # the same layer with the Etoy statistics computed by the edge kernel's tail (da_edge_layer_stats) instead of a separate pass
-    tail = engine.tail_stats_buffer(pm, B, Eb.device).fill_(float('nan'))
+    tail = engine.tail_stats_buffer(pm, B, n, Eb.device).fill_(float('nan'))
     tX, tE = engine.layer_main(pm, pm.layers[0], Xh_d, Eb, yh_d, nm_d, B, n, stats_out=tail)
     assert torch.equal(tX, gX) and torch.equal(tE, gE)
     fold = lambda t_: torch.stack([t_[:, :, 0].double().sum(1), t_[:, :, 1].double().sum(1), t_[:, :, 2].double().amin(1), t_[:, :, 3].double().amax(1)], 1)

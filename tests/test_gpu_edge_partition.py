@@ -80,7 +80,7 @@ def test_partition_variants_agree_and_match_oracle(B, n):
         nsplit = lib.da_edge_split_scratch_bytes(B, n, dx) if split_on else 0
         split = torch.full((nsplit,), 0xFF, dtype=torch.uint8, device=D) if nsplit > 0 else None      # NaN patterns: every slot read was written
         E_out = torch.empty_like(Ed); newX_in = torch.full((R, dx), float('nan'), device=D)
-        tail = engine.tail_stats_buffer(pm, B, Ed.device).fill_(float('nan'))
+        tail = engine.tail_stats_buffer(pm, B, n, Ed.device).fill_(float('nan'))
         L.check(lib.da_edge_layer_stats(L.ptr(Ed), L.ptr(E_out), L.ptr(Qm), _i(dx), L.ptr(kvf), L.ptr(nmd), L.ptr(ye2p1), L.ptr(ebias),
                                         L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']), C.c_float(1.0 / math.sqrt(dx // pm.n_head)),
                                         _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe), L.ptr(split), C.c_longlong(nsplit), L.ptr(tail),
@@ -113,7 +113,7 @@ def test_partition_variants_agree_and_match_oracle(B, n):
     # graph holds the skewed half-round rows and the split rows, the one before it the end of the full rounds.
     _tuning(threads=512)
     engine.SPLIT_TAIL = True
-    gX, gE = engine.layer_main(pm, lw, Xd, Ed, yd, nmd, B, n, stats_out=engine.tail_stats_buffer(pm, B, Ed.device))
+    gX, gE = engine.layer_main(pm, lw, Xd, Ed, yd, nmd, B, n, stats_out=engine.tail_stats_buffer(pm, B, n, Ed.device))
     torch.cuda.synchronize()
     assert torch.equal(gE, base_E)
     per = max(1, B // 8)

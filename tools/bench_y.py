@@ -15,7 +15,7 @@ model = DiscreteDenoisingDiffusion(make_cfg(FULL), make_info(), device=dev).eval
 pm = model.model._pack(dev)
 lw, nxt = pm.layers[0], pm.layers[1]
 y = torch.randn(B, pm.dy, device=dev); xy = torch.randn(B, pm.dy, device=dev)
-st = torch.randn(B, engine.N_TAIL_CHUNKS, 4, pm.de, device=dev).abs()
+st = torch.randn(B, engine.tail_chunks(n), 4, pm.de, device=dev).abs()
 out = torch.empty(B, pm.dy, device=dev); film = engine.film_buffers(pm, B, dev)
 xst = torch.randn(B, engine.N_XSTAT_CHUNKS, 4, pm.dx, device=dev).abs()
 
