@@ -240,15 +240,43 @@ __device__ __forceinline__ void block_matvec_T(const float* __restrict__ WT, con
     out[o] = relu ? fmaxf(s, 0.f) : s;
   }
 }
-__device__ __forceinline__ void block_layernorm(const float* x, const float* g, const float* b, float* out, int D) {
-  // D <= 256; every thread computes the statistics redundantly from LDS
-  float s = 0.f;
-  for (int k = 0; k < D; ++k) s += x[k];
-  const float mean = s / D;
-  float q = 0.f;
-  for (int k = 0; k < D; ++k) { const float d = x[k] - mean; q = fmaf(d, d, q); }
-  const float rstd = rsqrtf(q / D + 1e-5f);
+// out[o] = act(sum_k WT[k][o] v[k] + bias[o] + addc), WT (K,O) k-major, any O: one output per thread and pass, every load of a wave
+// is one contiguous 256-byte run (a (O,K) row-major weight read row-per-thread touches 64 cache lines per wave instruction:
+// lin_y1 took 15 us that way against 5.4 us for the equally large lin_y2 in this form).  K % 16 == 0 or the tail loop takes the rest.
+__device__ __forceinline__ void block_matvec_kmajor(const float* __restrict__ WT, const float* __restrict__ bias, const float* v,
+                                                    float* out, int O, int K, bool relu, float addc = 0.f) {
+  for (int o = threadIdx.x; o < O; o += blockDim.x) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = WT[(size_t)(k + u) * O + o];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u & 3] = fmaf(w[u], v[k + u], acc[u & 3]);
+    }
+    for (; k < K; ++k) acc[0] = fmaf(WT[(size_t)k * O + o], v[k], acc[0]);
+    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]) + (bias ? bias[o] : 0.f) + addc;
+    out[o] = relu ? fmaxf(s, 0.f) : s;
+  }
+}
+__device__ __forceinline__ void block_layernorm(const float* x, const float* g, const float* b, float* out, int D, float* red) {
+  // out = LN(x), D <= 256, x / out in LDS; red: 2 floats of LDS.  The first wave reduces (strided partial sums, then shuffles), the
+  // others wait: two barriers, no thread sums D values alone.  Ends synchronised.
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < D; k += 64) s += x[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / D;
+    float q = 0.f;
+    for (int k = threadIdx.x; k < D; k += 64) { const float d = x[k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    if (threadIdx.x == 0) { red[0] = mean; red[1] = rsqrtf(q / D + 1e-5f); }
+  }
   __syncthreads();
+  const float mean = red[0], rstd = red[1];
   for (int k = threadIdx.x; k < D; k += blockDim.x) out[k] = fmaf((x[k] - mean) * rstd, g[k], b[k]);
   __syncthreads();
 }
@@ -266,10 +294,18 @@ __global__ void __launch_bounds__(256) k_y_in(YInArgs a) {
   block_matvec(a.W1, a.dh, a.b1, hbuf, a.out + (size_t)b * a.dy, a.dy, a.dh, true);
 }
 
+// Diagnostic build only (EXP_Y_STAMP): wall-clock stamps (100 MHz) of the y chain's stages, workgroup 0 (tools/stamp_y.py)
+#ifdef EXP_Y_STAMP
+__device__ long long g_ystamps[32];
+#define YSTAMP(i) { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_ystamps[i] = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int da_debug_read_ystamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ystamps), sizeof(long long) * 32); }
+#else
+#define YSTAMP(i)
+#endif
 struct YFilmArgs {
   const float* y;                                     // (B,dy)
-  const float *We_add, *be_add, *We_mul, *be_mul;     // y_e_add / y_e_mul  (dx,dy)
-  const float *Wx_add, *bx_add, *Wx_mul, *bx_mul;     // y_x_add / y_x_mul  (dx,dy)
+  const float *We_add, *be_add, *We_mul, *be_mul;     // y_e_add / y_e_mul  weights TRANSPOSED (dy,dx)
+  const float *Wx_add, *bx_add, *Wx_mul, *bx_mul;     // y_x_add / y_x_mul  weights TRANSPOSED (dy,dx)
   const float *Wout, *bout;                           // e_out.weight TRANSPOSED (dx,de), e_out.bias
   float *ye2p1, *ebias, *yx1, *yx2p1;
   int dy, dx, de;
@@ -278,11 +314,26 @@ struct YFilmArgs {
 //   e_out(ye1 + (ye2+1)*Y) = e_out.W((ye2+1)*Y) + [e_out.b + e_out.W ye1]
 // v: y of graph b in LDS (dy floats); ye1: dx floats of LDS followed by blockDim.x floats of scratch
 __device__ __forceinline__ void y_film_body(const YFilmArgs& a, const float* v, float* ye1, int b) {
-  block_matvec(a.We_add, a.dy, a.be_add, v, ye1, a.dx, a.dy, false);
-  block_matvec(a.We_mul, a.dy, a.be_mul, v, a.ye2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
-  block_matvec(a.Wx_add, a.dy, a.bx_add, v, a.yx1 + (size_t)b * a.dx, a.dx, a.dy, false);
-  block_matvec(a.Wx_mul, a.dy, a.bx_mul, v, a.yx2p1 + (size_t)b * a.dx, a.dx, a.dy, false, 1.f);
+  // the four projections as ONE pass over 4 dx outputs (every thread busy at dx = 256 and 1,024 threads), weights k-major
+  for (int u = threadIdx.x; u < 4 * a.dx; u += blockDim.x) {
+    const int which = u / a.dx, o = u - which * a.dx;
+    const float* WT = which == 0 ? a.We_add : which == 1 ? a.We_mul : which == 2 ? a.Wx_add : a.Wx_mul;
+    const float* bb = which == 0 ? a.be_add : which == 1 ? a.be_mul : which == 2 ? a.bx_add : a.bx_mul;
+    float* dst = which == 0 ? ye1 : which == 1 ? a.ye2p1 + (size_t)b * a.dx : which == 2 ? a.yx1 + (size_t)b * a.dx : a.yx2p1 + (size_t)b * a.dx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 16 <= a.dy; k += 16) {
+      float w[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * a.dx + o];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q & 3] = fmaf(w[q], v[k + q], acc[q & 3]);
+    }
+    for (; k < a.dy; ++k) acc[0] = fmaf(WT[(size_t)k * a.dx + o], v[k], acc[0]);
+    dst[o] = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bb[o] + ((which & 1) ? 1.f : 0.f);
+  }
   __syncthreads();
+  YSTAMP(8)
   block_matvec_T(a.Wout, a.bout, ye1, a.ebias + (size_t)b * a.de, ye1 + a.dx, a.de, a.dx, false);   // Wout = e_out.weight^T (dx,de)
 }
 __global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
@@ -296,8 +347,8 @@ __global__ void __launch_bounds__(256) k_y_film(YFilmArgs a) {
 struct YUpdArgs {
   const float* y; const float* xstats; const float* estats;   // partials (B,nchunk,4,d): sum, sum of squares, min, max
   const float *WxyT, *bxy, *WeyT, *bey;               // x_y.lin^T (4dx,dy), e_y.lin^T (4de,dy)
-  const float *Wo0, *bo0, *Wo2, *bo2;                 // y_out.0 / .2
-  const float *n1g, *n1b, *W1, *b1, *W2T, *b2, *n2g, *n2b;   // norm_y1, lin_y1 (dff,dy), lin_y2^T (dff,dy), norm_y2
+  const float *Wo0, *bo0, *Wo2, *bo2;                 // y_out.0 / .2, weights TRANSPOSED (dy,dy)
+  const float *n1g, *n1b, *W1, *b1, *W2T, *b2, *n2g, *n2b;   // norm_y1, lin_y1^T (dy,dff), lin_y2^T (dff,dy), norm_y2
   float* out;
   int n, dx, de, dy, dff, nchunk_x, nchunk_e;
   const float* xy;                                    // (B,dy) x_y.lin(Xtoy statistics) precomputed by k_y_pre, or NULL: computed here
@@ -342,33 +393,42 @@ __device__ __forceinline__ void y_update_body(const YUpdArgs& a, const YFilmArgs
   float* hb = v2 + a.dy;                // dff
   float* scr = hb + a.dff;              // 4 * blockDim.x
   const int b = blockIdx.x, n = a.n;
+  YSTAMP(0)
   if (a.xy == nullptr) pooled_stats(a.xstats + (size_t)b * a.nchunk_x * 4 * a.dx, a.nchunk_x, a.dx, (double)n, sx, scr);
   pooled_stats(a.estats + (size_t)b * a.nchunk_e * 4 * a.de, a.nchunk_e, a.de, (double)n * n, se, scr);
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v0[k] = a.y[(size_t)b * a.dy + k];
   __syncthreads();
+  YSTAMP(1)
   if (a.xy == nullptr) block_matvec_T(a.WxyT, a.bxy, sx, v1, scr, a.dy, 4 * a.dx, false);
   else for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] = a.xy[(size_t)b * a.dy + k];
   __syncthreads();
   block_matvec_T(a.WeyT, a.bey, se, v2, scr, a.dy, 4 * a.de, false);
   __syncthreads();
+  YSTAMP(2)
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] = v0[k] + v1[k] + v2[k];
   __syncthreads();
-  block_matvec(a.Wo0, a.dy, a.bo0, v1, v2, a.dy, a.dy, true);
+  block_matvec_T(a.Wo0, a.bo0, v1, v2, scr, a.dy, a.dy, true);       // y_out.0 / .2, weights k-major, K split over the thread slices
   __syncthreads();
-  block_matvec(a.Wo2, a.dy, a.bo2, v2, v1, a.dy, a.dy, false);
+  block_matvec_T(a.Wo2, a.bo2, v2, v1, scr, a.dy, a.dy, false);
   __syncthreads();
+  YSTAMP(3)
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
   __syncthreads();
-  block_layernorm(v1, a.n1g, a.n1b, v0, a.dy);       // v0 = y after norm_y1
-  block_matvec(a.W1, a.dy, a.b1, v0, hb, a.dff, a.dy, true);
+  block_layernorm(v1, a.n1g, a.n1b, v0, a.dy, scr);  // v0 = y after norm_y1
+  YSTAMP(4)
+  block_matvec_kmajor(a.W1, a.b1, v0, hb, a.dff, a.dy, true);
   __syncthreads();
+  YSTAMP(5)
   block_matvec_T(a.W2T, a.b2, hb, v1, scr, a.dy, a.dff, false);
   __syncthreads();
+  YSTAMP(6)
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) v1[k] += v0[k];
   __syncthreads();
-  block_layernorm(v1, a.n2g, a.n2b, v2, a.dy);       // v2 = the layer's output y (LDS)
+  block_layernorm(v1, a.n2g, a.n2b, v2, a.dy, scr);  // v2 = the layer's output y (LDS)
   for (int k = threadIdx.x; k < a.dy; k += blockDim.x) a.out[(size_t)b * a.dy + k] = v2[k];
-  if (film != nullptr) y_film_body(*film, v2, sx, b); // sx .. : dx floats + blockDim.x floats of scratch (4 dx + 4 de + ... >= dx + 1024)
+  YSTAMP(7)
+  if (film != nullptr) y_film_body(*film, v2, sx, b);
+  YSTAMP(9) // sx .. : dx floats + blockDim.x floats of scratch (4 dx + 4 de + ... >= dx + 1024)
 }
 __global__ void __launch_bounds__(1024) k_y_update(YUpdArgs a) {
   extern __shared__ float sm[];

@@ -105,12 +105,13 @@ class PackedModel:
             Wqkv = torch.cat([g(a + '.q.weight'), g(a + '.k.weight'), g(a + '.v.weight')], 0)
             bqkv = torch.cat([g(a + '.q.bias'), g(a + '.k.bias'), g(a + '.v.bias')], 0)
             tr = lambda t: t.detach().float().t().contiguous().to(dev)      # transposed [K][O] for block_matvec_T
-            film = [f32(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
-                                            '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias')]
+            # every weight of the y chain is stored k-major ((in, out): consecutive threads read consecutive outputs)
+            film = [(tr if k.endswith('weight') else f32)(g(a + k)) for k in ('.y_e_add.weight', '.y_e_add.bias', '.y_e_mul.weight', '.y_e_mul.bias',
+                                                                              '.y_x_add.weight', '.y_x_add.bias', '.y_x_mul.weight', '.y_x_mul.bias')]
             film += [tr(g(a + '.e_out.weight')), f32(g(a + '.e_out.bias'))]
             yup = [tr(g(a + '.x_y.lin.weight')), f32(g(a + '.x_y.lin.bias')), tr(g(a + '.e_y.lin.weight')), f32(g(a + '.e_y.lin.bias')),
-                   f32(g(a + '.y_out.0.weight')), f32(g(a + '.y_out.0.bias')), f32(g(a + '.y_out.2.weight')), f32(g(a + '.y_out.2.bias')),
-                   f32(g(p + '.norm_y1.weight')), f32(g(p + '.norm_y1.bias')), f32(g(p + '.lin_y1.weight')), f32(g(p + '.lin_y1.bias')),
+                   tr(g(a + '.y_out.0.weight')), f32(g(a + '.y_out.0.bias')), tr(g(a + '.y_out.2.weight')), f32(g(a + '.y_out.2.bias')),
+                   f32(g(p + '.norm_y1.weight')), f32(g(p + '.norm_y1.bias')), tr(g(p + '.lin_y1.weight')), f32(g(p + '.lin_y1.bias')),
                    tr(g(p + '.lin_y2.weight')), f32(g(p + '.lin_y2.bias')), f32(g(p + '.norm_y2.weight')), f32(g(p + '.norm_y2.bias'))]
             self.layers.append(dict(
                 blob=pack.edge_layer_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev),
@@ -130,8 +131,8 @@ def _linear(A, lda, W, bias, rowmask, out, ldc, M, N, K, relu):
                               _i(K), _i(1 if relu else 0), L.stream()), 'da_linear')
 
 
-def edge_stats(E_bf16, B, n, de):
-    st = torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
+def edge_stats(E_bf16, B, n, de, out=None):
+    st = out if out is not None else torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
     L.check(L.lib().da_edge_stats(L.ptr(E_bf16), L.ptr(st), _i(B), _i(n), _i(de), _i(N_STAT_CHUNKS), L.stream()), 'da_edge_stats')
     return st
 

@@ -259,8 +259,8 @@ int da_y_in(const float* y, const float* W0, const float* b0, const float* W1, c
             int dh, int dy, void* stream);
 
 /* Per-layer FiLM vectors from y (layers.py:245-247,268-270): ye2p1 = 1+y_e_mul(y), ebias = e_out.b + e_out.W y_e_add(y),
- * yx1 = y_x_add(y), yx2p1 = 1+y_x_mul(y).  w = host array of 10 device pointers: y_e_add.{W,b}, y_e_mul.{W,b},
- * y_x_add.{W,b}, y_x_mul.{W,b}, e_out.{W TRANSPOSED (dx,de), b}. */
+ * yx1 = y_x_add(y), yx2p1 = 1+y_x_mul(y).  w = host array of 10 device pointers: y_e_add.{W^T,b}, y_e_mul.{W^T,b},
+ * y_x_add.{W^T,b}, y_x_mul.{W^T,b} (^T = stored (in,out) = (dy,dx)), e_out.{W TRANSPOSED (dx,de), b}. */
 int da_y_film(const float* y, const float* const* w /*host*/, float* ye2p1, float* ebias, float* yx1, float* yx2p1, int B,
               int dy, int dx, int de, void* stream);
 
@@ -323,7 +323,7 @@ int da_x_stats(const float* X, float* partials, int B, int n, int D, int nchunk,
 
 /* y' of one layer: new_y = y_out(y + Xtoy(X) + Etoy(E)); y = norm_y1(y + new_y); y = norm_y2(y + lin_y2(relu(lin_y1(y))))
  * (layers.py:277-281,346-359).  w = host array of 16 device pointers: x_y.lin.W^T, x_y.lin.b, e_y.lin.W^T, e_y.lin.b,
- * y_out.0.{W,b}, y_out.2.{W,b}, norm_y1.{w,b}, lin_y1.{W,b}, lin_y2.W^T, lin_y2.b, norm_y2.{w,b} (^T = stored (in,out)). */
+ * y_out.0.{W^T,b}, y_out.2.{W^T,b}, norm_y1.{w,b}, lin_y1.W^T, lin_y1.b, lin_y2.W^T, lin_y2.b, norm_y2.{w,b} (^T = stored (in,out)). */
 int da_y_update(const float* y, const float* xstats, const float* estats, const float* const* w /*host*/, float* out,
                 int B, int n, int dx, int de, int dy, int dff, int nchunk_x, int nchunk_e, void* stream);
 /* The part of da_y_update that does not depend on the layer's edge kernel: xy (B,dy) = x_y.lin(Xtoy statistics of the layer's input X)
