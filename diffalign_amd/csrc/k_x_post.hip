@@ -17,7 +17,13 @@ struct XPostCfg {
   static constexpr size_t BLOB_BYTES = (size_t)N_FR * 1024 + (size_t)N_PAR * 4;
 };
 
-constexpr int XP_WPB = 1;   // waves per workgroup: 600 one-wave workgroups spread over all CUs (35.6 us); 4 waves on 150 CUs: 40.1 us
+#ifndef XP_WPB_
+#define XP_WPB_ 4
+#endif
+// waves per workgroup.  Alone, 600 one-wave workgroups spread over all CUs are faster (35.6 us against 40.1 us for 4 waves on 150 CUs),
+// but every one of them takes a whole SIMD's registers, and the y chain's 1,024-thread workgroups that run beside this kernel then find
+// no CU to start on (engine._layers_node_on_main): with 4 the step is 1 - 2.6 % shorter.
+constexpr int XP_WPB = XP_WPB_;
 template <int DX, int DFF>
 __global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict__ newX_in, const float* __restrict__ X,
                                                 const uint8_t* __restrict__ mask, const uint4* __restrict__ blob,

@@ -37,6 +37,7 @@ def use_stats_tail(n: int) -> bool:
 
 
 Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
+NODE_ON_MAIN = os.environ.get('DA_NODE_ON_MAIN', '1') != '0'   # node chain on the caller's stream, y chain on the side stream (see _layers_node_on_main)
 FUSED_X_IN = os.environ.get('DA_FUSED_X_IN', '1') != '0'   # node input stage as one kernel (da_x_in) instead of two da_linear + da_x_in_finish
 TABLE_IN = os.environ.get('DA_TABLE_IN', '1') != '0'       # first edge layer reads its input from the input stage's table (da_edge_in_classes / da_edge_layer_table)
 EARLY_QKV0 = os.environ.get('DA_EARLY_QKV0', '1') != '0'   # layer 0's q/k/v and Xtoy term behind the node input path (A/B switch)
@@ -315,6 +316,67 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre, table0=None):
+    """The layer stack with the NODE chain on the caller's stream (merge, node tail of layer l, q/k/v of layer l+1 directly behind the
+    edge kernel and in front of the next one: no cross-stream event on it) and the y chain on the side stream (edge kernel -> event ->
+    y_update(l) + FiLM(l+1) [+ the separate statistics pass of small graphs] -> event the next edge kernel waits on).  Since the y
+    chain's kernel takes 25 us instead of 46 (k-major weights, wave-level LayerNorms) it ends before the node chain does, so its two
+    events are off the critical path, provided its 1,024-thread workgroups find free CUs: da_x_post runs four row tiles per
+    workgroup (150 CUs at 19,200 rows) instead of 600 single-wave workgroups that take a whole SIMD's registers each on every CU.
+    Gap between two edge kernels 134 -> 115 us; steps in alternating same-box runs: 13.16 -> 13.01 ms (headline), 4.02 -> 3.91 ms
+    (B = 64, n = 140), 2.70 -> 2.65 ms (B = 100, n = 72), 7.26 -> 7.11 ms (USPTO-like).  DA_NODE_ON_MAIN=0: _layers_y_on_main.
+    `pre` = (Qm, kvf, xst, xy) of layer 0 from the input stage (model_forward)."""
+    dev = Xh.device
+    Qm, kvf, xst, xy = pre
+    if y_done0 is not None:
+        main.wait_event(y_done0)                     # FiLM vectors of layer 0 (y stream of the input stage)
+    xs_done = None                                   # Xtoy term of the coming layer complete (third stream)
+    st_pass = None                                   # statistics of this layer's input from a separate pass (graphs too small for the tail)
+    keep = []
+    for li, lw in enumerate(pm.layers):
+        nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
+        tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
+        st = st0 if li == 0 else (tail if tail is not None else st_pass)
+        st_next = (torch.empty(B, N_STAT_CHUNKS, 4, pm.de, dtype=torch.float32, device=dev)
+                   if nxt is not None and not use_stats_tail(n) else None)
+        X_next = torch.empty(B, n, pm.dx, device=dev)
+        y_next = torch.empty(B, pm.dy, device=dev)
+        film_next = film_buffers(pm, B, dev) if nxt is not None else None
+        qkv_next = _qkv_buffers(pm, B, n, dev) if nxt is not None else None
+        xst_next = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev) if nxt is not None else None
+        xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
+        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None)
+        ev_edge = main.record_event()
+        with torch.cuda.stream(side):                # y chain
+            side.wait_event(ev_edge)
+            if xs_done is not None:
+                side.wait_event(xs_done)             # xy of this layer (recorded one edge kernel ago)
+            y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
+            if st_next is not None:
+                edge_stats(E_next, B, n, pm.de, out=st_next)
+            ev_y = side.record_event()
+        _x_post(pm, lw, newX_in, Xh, nm, B, n, out=X_next)
+        if nxt is not None:
+            ev_xp = main.record_event()
+            with torch.cuda.stream(side2):           # next layer's Xtoy statistics and their x_y.lin term beside its q/k/v
+                side2.wait_event(ev_xp)
+                node_stats(pm, X_next, B, n, out=xst_next)
+                y_pre(pm, nxt, xst_next, B, n, xy_next)
+                xs_done = side2.record_event()
+            _qkv(pm, nxt, X_next, nm, B, n, out=qkv_next)
+        main.wait_event(ev_y)                        # FiLM vectors of the next layer / the stack's y output
+        keep.append((Xh, Eh, yh, film, Qm, kvf, xst, xy, st, newX_in, split))
+        if len(keep) > 2:
+            keep.pop(0)                              # layer l-2: every reader of its buffers has been joined since
+        Xh, Eh, yh, film, xst, xy, st_pass = X_next, E_next, y_next, film_next, xst_next, xy_next, st_next
+        if nxt is not None:
+            Qm, kvf = qkv_next
+    if xs_done is not None:
+        main.wait_event(xs_done)
+    del keep
+    return Xh, Eh, yh
+
+
 def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre=None, table0=None):
     """The layer stack with three streams.  Between two edge kernels two chains run: the y branch (y_update(l) needs the Etoy
     statistics the edge kernel of layer l leaves, then the FiLM vectors of layer l+1: ~100 us, 64 small workgroups) and the node chain
@@ -487,7 +549,9 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
-        if Y_ON_MAIN:
+        if Y_ON_MAIN and NODE_ON_MAIN and pre is not None:
+            Xh, Eh, yh = _layers_node_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre, table0=table0)
+        elif Y_ON_MAIN:
             Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre=pre, table0=table0)
         else:
             # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
