@@ -99,6 +99,17 @@ def test_model_forward_and_sampling_with_extra_features():
                        atom_map_numbers=true['atom_map_numbers'].to(D), mol_assignments=true['mol_assignments'].to(D))
     out = model.sample_one_batch(data=data)
     assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
+    # the chain keeps the fixed side's share of the eigensolver between steps (EigCache): the same seeds give the same samples, bit for
+    # bit, with the cache switched off
+    from diffalign_amd import extra_features as XF
+    seeds = torch.arange(3, device=D) + 77
+    with_cache = model.sample_one_batch(data=data, chain_seeds=seeds)
+    XF.EIG_CACHE = False
+    try:
+        without = model.sample_one_batch(data=data, chain_seeds=seeds)
+    finally:
+        XF.EIG_CACHE = True
+    assert torch.equal(with_cache.X, without.X) and torch.equal(with_cache.E, without.E)
 
 
 def _solve(Lap, nm, pn):
