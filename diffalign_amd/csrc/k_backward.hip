@@ -555,7 +555,13 @@ __global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ pa
   const size_t stride = isW ? (size_t)nW : (size_t)nB;
   float sum = 0.f;
   if (isW || isB)
-    for (int g = g0; g < g1; ++g) sum += src[(size_t)g * stride];
+    for (int g = g0; g < g1; g += 16) {                 // sixteen partials in flight, added in slice order (same sum, bit for bit)
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = g + q < g1 ? src[(size_t)(g + q) * stride] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (g + q < g1) sum += v[q];
+    }
   s_p[gg][ol] = sum;
   __syncthreads();
   if (gg == 0 && (isW || isB)) {
