@@ -58,3 +58,20 @@ def test_sparse_fields_and_text_formats(tmp_path):
     f2 = str(tmp_path / 'eval.txt')
     graph.save_samples_to_file_without_weighted_prob(f2, 4, {'a': [dict(rxn='A>>B', elbo=1.5, loss_t=1.0, loss_0=0.5, count=3)]}, ['A>>B'])
     assert open(f2).read() == "(cond 4) A>>B:\n\t('A>>B', [1.5, 1.0, 0.5, 3])\n"
+
+
+def test_statistics_tail_policy_and_fixed_block_of_the_eigen_cache():
+    """Host logic of two round-2 switches.  engine.tail_chunks / use_stats_tail: about 1,300 pairs per ticket, between 4 and 64 tickets
+    per graph, the tail from n = 112 on.  EigCache.from_free_masks: the fixed block of a graph starts behind its last node that is real
+    and free to diffuse (padding and condition nodes behind it belong to the block); sizes and state of the cache."""
+    import torch
+    from diffalign_amd import engine
+    from diffalign_amd.extra_features import EigCache
+    if engine._TAIL_CHUNKS_ENV is None and engine._STATS_TAIL_ENV is None:
+        assert [engine.tail_chunks(n) for n in (20, 72, 140, 300, 1000)] == [4, 4, 15, 64, 64]
+        assert [engine.use_stats_tail(n) for n in (72, 111, 112, 300)] == [False, False, True, True]
+    node_mask = torch.tensor([[1, 1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1, 1], [1, 1, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    free_e = torch.tensor([[1, 1, 0, 0, 0, 0, 0], [1, 0, 1, 0, 0, 0, 1], [0, 0, 1, 1, 0, 0, 0]], dtype=torch.bool)
+    c = EigCache.from_free_masks(free_e, node_mask)
+    assert c.fixed_from.tolist() == [2, 7, 0]          # graph 1: a free node at the very end, nothing to keep; graph 2: nothing free
+    assert c.mmax == 7 and c.store.shape == (3, 9, 7) and c.state.tolist() == [0, 0, 0]
