@@ -245,14 +245,20 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
       tmax = fmaxf(tmax, ((vbits >> b0) & 1u) ? y.x : -INFINITY);
       tmax = fmaxf(tmax, ((vbits >> b1) & 1u) ? y.y : -INFINITY);
     } else {
+#ifndef EXP_NOSHIFT
       tmax = fmaxf(tmax, fmaxf(y.x, y.y));
+#endif
     }
     pin(y);
     e1[2 * k] = y.x; e1[2 * k + 1] = y.y;
 #if !defined(EXP_LATEKV) && !defined(EXP_NOKV)
     if (k == 3) kv[0] = kv_next[0];                  // first K word group is dead: fetch the next block's now
 #endif
+#ifdef EXP_NOSHIFT
+    if (k & 1) { feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
+#else
     if (k & 1) { pin(tmax); feed.step(fs++); __builtin_amdgcn_sched_barrier(0); }
+#endif
   }
 #ifndef EXP_NOKV
 #ifndef EXP_LATEKV
@@ -274,8 +280,12 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
     if (k & 1) v2 = f32x2{__builtin_bit_cast(float, vv[2 * m]), __builtin_bit_cast(float, vv[2 * m + 1])};
     else v2 = f32x2{bf16_lo(vv[2 * m]), bf16_lo(vv[2 * m + 1])};
     const f32x2 y = {e1[2 * k], e1[2 * k + 1]};
+#ifdef EXP_NOSHIFT
+    f32x2 p = {EXP2F(y.x), EXP2F(y.y)};
+#else
     const f32x2 arg = y * LOG2E - mref2;
     f32x2 p = {EXP2F(arg.x), EXP2F(arg.y)};
+#endif
     if (MASKED) {
       const int b0 = ((2 * k) & 3) + 8 * ((2 * k) >> 2), b1 = b0 + 1;
       p.x = ((vbits >> b0) & 1u) ? p.x : 0.f;
@@ -301,6 +311,9 @@ __device__ __forceinline__ void softmax_film_block(const int cb, const int lane,
 #endif
 #endif
   STAMP(8)   // loop 2: exp, sums, FiLM (+ 4 feed MFMAs)
+#ifdef EXP_NOSHIFT
+  if (!MASKED) { sm_l += psum.x + psum.y; sm_a += pv.x + pv.y; sm_m = 0.f; return; }
+#endif
   sm_l = fmaf(sm_l, sc, psum.x + psum.y);
   sm_a = fmaf(sm_a, sc, pv.x + pv.y);
   sm_m = mnew;
@@ -815,6 +828,9 @@ static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
 }
 static int edge_grid(int rows) {
   int grid = 256;                                   // one persistent workgroup per CU
+#ifdef EXP_GRID
+  { const char* e = getenv("DA_EDGE_GRID"); if (e) grid = atoi(e); }   // timing experiment: fewer CUs (clock / power probe)
+#endif
   int need = ((rows + 3) / 4 + 7) / 8 * 8;          // enough workgroups for one row per wave
   if (need < grid) grid = need < 8 ? 8 : need;
   return grid;
