@@ -53,6 +53,17 @@ def make_info():
               node_types=torch.ones(len(ATOM_DECODER)), edge_types=torch.ones(len(BOND_DECODER)))
 
 
+def edge_kernel_source_hash():
+    """sha256 over the sources of k_edge_layer (the kernel file and the headers it includes), as stored beside the PMC numbers."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diffalign_amd', 'csrc')
+    for f in ('k_edge_layer.hip', 'mfma_util.h', 'common.h', 'edge_in_layout.h'):
+        with open(os.path.join(csrc, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement of the reference, oracle/oracle.py) timed on this host: same network, same step,
     a bounded sample of the same workload (graphs of the benchmark's own size n=300, P=144, one at a time, for about
@@ -94,7 +105,7 @@ def cpu_baseline(seconds_budget=25.0):
                       f'B={B} graph at n={n} (the graph size of the GPU workload) in {dt:.1f}s'}
 
 
-def train_main(args, dev, dist, world, rank):
+def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None):
     """BASELINE.json configs[3]: data-parallel training steps of the align_absorbing denoiser (9 layers, 8.18M parameters, dropout
     0.2 as configs/neuralnet/default.yaml) on synthetic USPTO-like graphs; every rank holds its own batch, the only collective is the
     SUM all-reduce of the 32.7 MB flat gradient.  Reported as training graphs/s over all ranks; not the headline metric."""
@@ -123,12 +134,13 @@ def train_main(args, dev, dist, world, rank):
         torch.cuda.synchronize()
 
     losses = []
-    for _ in range(args.warmup):
+    steps = args.steps if steps is None else steps
+    for _ in range(args.warmup if warmup is None else warmup):
         step_fn()
     sync()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         losses.append(step_fn().clone())
     sync()
     dt = time.perf_counter() - t0
@@ -136,9 +148,12 @@ def train_main(args, dev, dist, world, rank):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if not emit:
+        return {'train_ms_per_step': dt / steps * 1e3, 'train_workload': f'B={B}, n={n}, loss {args.train_loss}, {TRAIN_PRECISION} forward/backward, '
+                                                                          f'AdamW(amsgrad); {steps} steps', 'train_graphs_per_s': B * steps / dt}
     if rank == 0:
-        print(json.dumps({'metric': 'training graphs/sec per node (align_absorbing, data parallel)', 'value': B * args.steps * world / dt,
-                          'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        print(json.dumps({'metric': 'training graphs/sec per node (align_absorbing, data parallel)', 'value': B * steps * world / dt,
+                          'unit': 'graphs/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                           'config': {'workload': f'NOT the headline -- BASELINE.json configs[3]: align_absorbing training step, loss {args.train_loss}, '
                                                  f'batch {B}/GPU padded to n={n} (USPTO-like sizes), dropout 0.2, AdamW(amsgrad), extra features and '
@@ -149,6 +164,54 @@ def train_main(args, dev, dist, world, rank):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+TRAIN_PRECISION = 'fp32'
+
+
+def loop_object(args, model, step, z_t, data, masks, dev):
+    """What the headline leaves out of a real sampling loop, measured in the same process right after it: the same reverse step with
+    the 8 + 12 extra features computed on the device inside it (as sample_one_batch runs it; the headline takes them as inputs, SURVEY
+    8d), the feature set and its eigensolver alone, and one training step (configs[3])."""
+    from diffalign_amd import extra_features as XF
+    out = {}
+    saved = model.extra_features_fn
+    model.extra_features_fn = None
+    z_t.eig_cache = XF.EigCache.from_free_masks(masks[1], data.node_mask)
+    evs, orig = [], XF._eigen
+
+    def timed_eigen(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig(*a, **k); e1.record(); evs.append((e0, e1))
+        return r
+
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            out['ms_per_step'] = (time.perf_counter() - t0) / args.steps * 1e3
+            out['graph_steps_per_s'] = z_t.X.shape[0] * 1e3 / out['ms_per_step']
+            XF._eigen = timed_eigen
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.compute_extra_data(z_t)
+            torch.cuda.synchronize()
+            out['extra_features_ms'] = (time.perf_counter() - t0) / args.steps * 1e3
+            out['eigensolver_ms'] = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
+            out['eigensolver_share_of_step'] = out['eigensolver_ms'] / out['ms_per_step']
+    finally:
+        XF._eigen = orig
+        model.extra_features_fn = saved
+        z_t.eig_cache = None
+    out['what'] = ('ms_per_step: the headline step with --extra-features device (features + eigensolver inside the step, fixed block kept '
+                   'along the chain); extra_features_ms / eigensolver_ms: the whole feature set / k_extra_eig_solve alone, back to back')
+    return out
 
 
 TABLE_PREFETCH = os.environ.get('DA_TABLE_PREFETCH', '1') != '0'   # A/B switch: per-step transition tables as slices of tables laid out once (reverse_step t_int=)
@@ -174,6 +237,11 @@ def main():
     ap.add_argument('--train-batch', type=int, default=16)
     ap.add_argument('--train-nodes', type=int, default=140)
     ap.add_argument('--train-loss', choices=['ce', 'vb', 'vbce'], default='vb')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with --gpus 1: create a world-size-1 nccl (RCCL) process group anyway and take the multi-GPU branch (barrier, final '
+                         'gather inside the timed region, MAX all-reduce of the time) -- a single-GPU rehearsal of what every rank of an N-GPU run does')
+    ap.add_argument('--no-loop', action='store_true', help="skip the 'loop' object (the same step with the extra features computed on the device, "
+                                                           'the eigensolver alone, one training step), measured after the headline')
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
     args = ap.parse_args()
 
@@ -199,10 +267,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group('nccl', device_id=dev)
+        if 'MASTER_ADDR' in os.environ and 'RANK' in os.environ:
+            dist.init_process_group('nccl', device_id=dev)
+        else:                                                  # --force-dist outside a launcher: a group of this one process
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
 
     from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
     from diffalign_amd.placeholder import PlaceHolder
@@ -300,28 +375,29 @@ def main():
     t_s = edge_ms * 1e-3
     tf = flops_launch / t_s / 1e12 if t_s > 0 else 0.0
     gbs = bytes_launch / t_s / 1e9 if t_s > 0 else 0.0
-    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per the gfx950 note in
-    # MI355X_MICROARCH.md), valid for the workload they were taken on only
-    traffic = None
+    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic_bench.sh + tools/traffic_json.py; FETCH_SIZE doubled per the
+    # gfx950 note in MI355X_MICROARCH.md).  Valid only for the workload AND the kernel source they were taken on: the file carries the
+    # sha256 of the kernel's sources, and a different hash (or workload) gives traffic = null instead of a stale number.
+    traffic, traffic_note = None, None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02', 'edge_layer_traffic.json')) as f:
+        here = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(here, 'profiles', 'r03', 'edge_layer_traffic.json')) as f:
             tj = json.load(f)
-        if tj['workload'] == {'B': B, 'n': n} and args.workload == 'full':
-            # mean over the step's launches: the first layer (bare kernel, or the table-input instantiation that reads no hidden
-            # input) and the layers >= 1 that run the kernel with its statistics tail
-            first = tj['hbm_bytes_per_launch']
-            if engine.TABLE_IN and 'table_input_first_layer' in tj:
-                first = tj['table_input_first_layer']['hbm_bytes_per_launch']
-            traffic = first
-            if engine.use_stats_tail(n) and 'with_stats_tail' in tj:
-                nl = len(model.model.tf_layers)
-                traffic = (first + (nl - 1) * tj['with_stats_tail']['hbm_bytes_per_launch']) / nl
-    except (OSError, KeyError, ValueError):
+        if tj.get('kernel_source_sha256') != edge_kernel_source_hash():
+            traffic_note = 'profiles/r03/edge_layer_traffic.json was measured on a different k_edge_layer source: not reported'
+        elif tj['workload'] == {'B': B, 'n': n} and args.workload == 'full' and engine.TABLE_IN == bool(tj.get('table_input_first_layer')):
+            nl = len(model.model.tf_layers)
+            first = tj['table_input_first_layer']['hbm_bytes_per_launch']
+            rest = tj['with_stats_tail' if engine.use_stats_tail(n) else 'bare']['hbm_bytes_per_launch']
+            traffic = (first + (nl - 1) * rest) / nl      # mean over the step's launches
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
             'algorithmic_bytes_per_launch': bytes_launch, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
+    if traffic_note:
+        roof['traffic_note'] = traffic_note
     if engine.use_stats_tail(n):
         roof['note'] = ('launches of layers >= 1 include the Etoy statistics tail (da_edge_layer_stats: early-finishing waves stream '
                         'E_in a second time, +0.74 GB and +0.06 to +0.12 ms per launch) that replaces a separate 0.155 ms pass; '
@@ -337,6 +413,14 @@ def main():
                           'extra_features': 'given as inputs (SURVEY 8d)' if args.extra_features == 'inputs' else 'computed on the device inside the step',
                           'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)'},
                'roofline': roof}
+        if world == 1 and not args.no_loop and args.extra_features == 'inputs' and not args.graph:
+            out['loop'] = loop_object(args, model, step, z_t, data, masks, dev)
+            del model, z_t
+            torch.cuda.empty_cache()
+            try:
+                out['loop'].update(train_main(args, dev, None, 1, 0, emit=False, steps=3, warmup=2))
+            except Exception as e:                             # the training leg must never take the headline line down with it
+                out['loop']['train_error'] = f'{type(e).__name__}: {e}'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

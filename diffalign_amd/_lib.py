@@ -16,12 +16,14 @@ LIB_PATH = os.environ.get('DA_LIB') or os.path.join(_HERE, 'libdiffalign_hip.so'
 _lib: Optional[C.CDLL] = None
 
 c_f = C.c_void_p  # all device pointers travel as void*
+ABI_VERSION = 3      # DA_ABI_VERSION of include/diffalign_hip.h this binding was written against
 
 # Signatures of include/diffalign_hip.h, 'return:arguments' with p = pointer (void*), i = int, q = long long, f = float,
 # s = const char*; set on the library once, so that no call site can truncate a size or pass a float as a double
 # (tests/test_abi_exports.py checks this table against the header).
 SIGNATURES = {
     'da_abi_version': 'i:',
+    'da_init': 'i:',
     'da_last_error': 's:',
     'da_mask_dense': 'i:pppiiiip',
     'da_collapse': 'i:pppppiiiip',
@@ -74,8 +76,6 @@ SIGNATURES = {
     'da_x_out_finish': 'i:pipipppiiip',
     'da_edge_out': 'i:ppipppppiiiiip',
     'da_edge_out_tiles': 'i:ppipppppiiiiip', 'da_edge_out_sample': 'i:ppipppppppppfppqpppiiiiip',
-    'da_edge_out_g': 'i:pppiiiip',
-    'da_edge_out_finish': 'i:ppippppiiip',
     'da_extra_adjacency': 'i:pppppppiiip',
     'da_extra_cycles': 'i:ppppppiip',
     'da_extra_eigen': 'i:ppqqppppppiip',
@@ -110,6 +110,14 @@ def lib() -> C.CDLL:
                 raise DiffAlignHipError(f'{LIB_PATH} does not export {name}: rebuild it (python -m diffalign_amd.build)') from None
             fn.restype = _CT[ret]
             fn.argtypes = [_CT[a] for a in args]
+        if _lib.da_abi_version() != ABI_VERSION:
+            v, _lib = _lib.da_abi_version(), None
+            raise DiffAlignHipError(f'{LIB_PATH} has ABI version {v}, this binding expects {ABI_VERSION}: rebuild it (python -m diffalign_amd.build)')
+        if torch.cuda.is_available():
+            # per-device set-up that must not happen under stream capture (da_edge_in_sym_static's scratch address), for the current device;
+            # a process that uses several devices calls da_init() once with each of them current
+            if _lib.da_init() != 0:
+                raise DiffAlignHipError('da_init failed: ' + _lib.da_last_error().decode())
     return _lib
 
 

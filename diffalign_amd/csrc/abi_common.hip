@@ -13,5 +13,7 @@ void da_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* da_last_error(void) { return g_err; }
-int da_abi_version(void) { return 1; }
+// 3 (round 3): da_init added, the two-pass output stage (da_edge_out_g / da_edge_out_finish) removed; 2 (round 2, not bumped at the time):
+// da_y_film / da_y_update* take the y-chain weights k-major ((in, out)), da_edge_layer_stats resets its ticket word itself
+int da_abi_version(void) { return 3; }
 }

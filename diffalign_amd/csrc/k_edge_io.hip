@@ -379,74 +379,13 @@ __global__ void __launch_bounds__(256) k_edge_out(const bf16_t* __restrict__ E_h
   }
 }
 
-// ---- output stage in two passes (each hidden edge row read ONCE, each mlp_out_E evaluated ONCE):
-//   pass 1  G[b,i,j,0:8] = mlp_out_E(E_h[b,i,j])                      (k_edge_out_g: one wave per query row, 32-pair tiles)
-//   pass 2  logits = sym((G + E_in[..., :Ke]) * offdiag) (+ skip)      (k_edge_out_finish: 32x32 tiles, mirror through LDS)
-template <int DE, int HE>
-__global__ void __launch_bounds__(256) k_edge_out_g(const bf16_t* __restrict__ E_h, const uint4* __restrict__ blob,
-                                                    float* __restrict__ G, int B, int n) {
-  using C = EdgeIoCfg<DE, HE>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* sW = reinterpret_cast<uint4*>(smem);
-  for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += 256) sW[t] = blob[t];
-  __syncthreads();
-  const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * C::KS1 * 64;
-  const float* sP = reinterpret_cast<const float*>(sW + C::OUT_FR * 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int NT = (n + 31) / 32, R = B * n;
-  for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
-    for (int jt = 0; jt < NT; ++jt) {
-      const int jl = jt * 32 + r; const bool jvalid = jl < n; const int jc = jvalid ? jl : n - 1;
-      f32x16 o;
-      mlp_out_chain<DE, HE>(E_h + ((size_t)row * n + jc) * DE, h, lane, sW0, sW1, sP, o);
-      // accumulator rows crow(e,h), e < 4, are classes 4h .. 4h+3: one 16-byte store per lane, 32 B per pair
-      if (jvalid) *reinterpret_cast<float4*>(G + ((size_t)row * n + jl) * 8 + 4 * h) = float4{o[0], o[1], o[2], o[3]};
-    }
-  }
-}
-
-// one workgroup per (b, 32x32 tile of ordered pairs); the mirrored tile travels through LDS so that both reads are row-wise
-__global__ void __launch_bounds__(256) k_edge_out_finish(const float* __restrict__ G, const float* __restrict__ E_in, int de_in,
-                                                         const int* __restrict__ src, const float* __restrict__ s1p,
-                                                         const float* __restrict__ s2p, float* __restrict__ E_o, int n, int Ke) {
-  __shared__ float sM[32][32][8 + 1];              // mirrored tile: (G + E_in)[b, j, i, c] at [j - j0][i - i0][c]
-  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const size_t base = (size_t)b * n * n;
-  const float s1 = src ? s1p[0] : 0.f, s2 = src ? s2p[0] : 0.f;
-  for (int t = threadIdx.x; t < 32 * 32; t += 256) {          // t = (jj, ii): rows j of the mirrored tile, ii contiguous
-    const int jj = t >> 5, ii = t & 31, j = j0 + jj, i = i0 + ii;
-    if (j < n && i < n) {
-      const size_t q = base + (size_t)j * n + i;
-      const float4 a0 = *reinterpret_cast<const float4*>(G + q * 8), a1 = *reinterpret_cast<const float4*>(G + q * 8 + 4);
-      const float g8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      for (int c = 0; c < Ke; ++c) sM[jj][ii][c] = g8[c] + E_in[q * de_in + c];
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < 32 * 32; t += 256) {          // t = (ii, jj): rows i of the direct tile, jj contiguous
-    const int ii = t >> 5, jj = t & 31, i = i0 + ii, j = j0 + jj;
-    if (i >= n || j >= n) continue;
-    const size_t p = base + (size_t)i * n + j;
-    const float4 a0 = *reinterpret_cast<const float4*>(G + p * 8), a1 = *reinterpret_cast<const float4*>(G + p * 8 + 4);
-    const float g8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const int si = src ? src[b * n + i] : -1, sj = src ? src[b * n + j] : -1;
-    const bool aligned = si >= 0 && sj >= 0;
-    const float* ealn = aligned ? E_in + (base + (size_t)si * n + sj) * de_in : nullptr;
-    for (int c = 0; c < Ke; ++c) {
-      float v = (j == i) ? 0.f : 0.5f * ((g8[c] + E_in[p * de_in + c]) + sM[jj][ii][c]);
-      if (src) v += aligned ? s1 * ealn[c] : (c == 0 ? s2 : 0.f);
-      E_o[p * Ke + c] = v;
-    }
-  }
-}
-
 // ---- output stage in ONE pass over mirrored tiles: one workgroup per pair of 32x32 tiles (it <= jt) of one graph.
 //   phase 1  tile (jt, it), rows j:  sB[j][i] = mlp_out_E(E_h[b,j,i]) + E_in[b,j,i]        (LDS, 32 KiB)
 //   phase 2  tile (it, jt), rows i:  logits(i,j) = sym part + skip, written from registers; the symmetric part goes back
 //            into sB[j][i] in place (each element is read and rewritten by the same lane)
 //   phase 3  tile (jt, it) written row-wise from LDS (+ its own skip term); skipped on diagonal tiles
 // Every hidden edge row is read once, row-wise, and no intermediate reaches HBM.  Same arithmetic per element as
-// k_edge_out / k_edge_out_finish (a + b == b + a): bit-identical logits.
+// k_edge_out (a + b == b + a): bit-identical logits (tests).
 // SAMPLE (da_edge_out_sample, Ke == 7): the reverse step's edge half replaces the logits output.  Phase 2 leaves the finished
 // logits of tile (it, jt) (skip term included) in LDS instead of HBM; then every thread takes upper-triangle pairs (i < j) of the
 // tile, evaluates the posterior over the 7x7 tables (posterior_elem_tab: k_posterior_E_tiles' arithmetic, same bits) and draws the
@@ -779,6 +718,35 @@ int da_edge_in_sym(const float* E_in, int de_in, const uint8_t* node_mask, const
   return DA_OK;
 }
 
+}  // extern "C"
+// Device address of g_edge_in_scratch on the device that owns `stream` (the current device for the null stream), resolved once per
+// device with hipGetSymbolAddress (each GPU holds its own copy of the array at its own address) and kept.  da_init() resolves it
+// ahead of time, so that the first da_edge_in_sym_static call of a device may already be under stream capture.
+static int edge_in_static_scratch(hipStream_t stream, uint8_t** out) {
+  static uint8_t* ptr_of_device[DA_MAX_DEVICES];
+  int dev = 0, sdev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_edge_in_sym_static: no current HIP device"); return DA_ERR_HIP; }
+  if (stream != nullptr && hipStreamGetDevice(stream, &sdev) == hipSuccess && sdev != dev) {
+    da_set_error("da_edge_in_sym_static: the stream belongs to device %d but device %d is current", sdev, dev);
+    return DA_ERR_ARG;
+  }
+  uint8_t* p = __atomic_load_n(&ptr_of_device[dev], __ATOMIC_ACQUIRE);
+  if (p == nullptr) {
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_edge_in_scratch));
+    if (e != hipSuccess || p == nullptr) { da_set_error("da_edge_in_sym_static: hipGetSymbolAddress: %s", hipGetErrorString(e)); return DA_ERR_HIP; }
+    __atomic_store_n(&ptr_of_device[dev], p, __ATOMIC_RELEASE);
+  }
+  *out = p;
+  return DA_OK;
+}
+extern "C" {
+// Per-device set-up that must not happen under stream capture: resolves the static scratch of da_edge_in_sym_static on the CURRENT
+// device.  Call once per device (diffalign_amd/_lib.py does, for the current device, when it loads the library on a GPU machine).
+int da_init(void) {
+  uint8_t* p = nullptr;
+  return edge_in_static_scratch(nullptr, &p);
+}
+
 // da_edge_in_sym for callers that cannot allocate (HIP graph capture, serving loops): the scratch is a static device array of the
 // library instead of a workspace argument.  No hipMalloc / hipFree; B <= DA_EDGE_IN_STATIC_MAX_B.  The array belongs to the
 // device: calls on one GPU share it, so calls that overlap on one GPU (different streams) race; it is rewritten by every call.
@@ -789,15 +757,8 @@ int da_edge_in_sym_static(const float* E_in, int de_in, const uint8_t* node_mask
   DA_CHECK_ARG(de_in >= 1 && de_in <= 16 && de >= 8 && de <= 64, "da_edge_in_sym_static: widths (de_in=%d, de=%d) outside the static scratch's layout", de_in, de);
   if (B == 0 || n == 0) return DA_OK;
   DA_CHECK_ARG((size_t)da_edge_in_scratch_bytes(B, de_in, de) <= sizeof(g_edge_in_scratch), "da_edge_in_sym_static: scratch too small");
-  static uint8_t* ptr_of_device[DA_MAX_DEVICES];      // device address of g_edge_in_scratch, per GPU (each holds its own copy)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_edge_in_sym_static: no current HIP device"); return DA_ERR_HIP; }
-  uint8_t* scratch = __atomic_load_n(&ptr_of_device[dev], __ATOMIC_ACQUIRE);
-  if (scratch == nullptr) {
-    hipError_t e = hipGetSymbolAddress((void**)&scratch, HIP_SYMBOL(g_edge_in_scratch));
-    if (e != hipSuccess || scratch == nullptr) { da_set_error("da_edge_in_sym_static: hipGetSymbolAddress: %s", hipGetErrorString(e)); return DA_ERR_HIP; }
-    __atomic_store_n(&ptr_of_device[dev], scratch, __ATOMIC_RELEASE);
-  }
+  uint8_t* scratch = nullptr;
+  if (int rc = edge_in_static_scratch((hipStream_t)stream, &scratch)) return rc;
   return da_edge_in_sym(E_in, de_in, node_mask, blob, E_h, scratch, B, n, de, he, stream);
 }
 
@@ -859,29 +820,6 @@ int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void
         (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, nullptr, n, ke, sa);
   else { da_set_error("da_edge_out_sample: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_out_sample");
-  return DA_OK;
-}
-
-// Output stage in two passes (see k_edge_out_g): G (B,n,n,8) fp32 scratch owned by the caller.
-//   da_edge_out_g:      G = mlp_out_E(E_h) per ordered pair            transformer_model_with_y.py:672-673
-//   da_edge_out_finish: logits = sym((G + E_in[..., :ke]) * offdiag) [+ skip]          :674-704
-int da_edge_out_g(const void* E_h, const void* blob, float* G, int B, int n, int de, int he, void* stream) {
-  if (B == 0 || n == 0) return DA_OK;
-  hipStream_t s = (hipStream_t)stream;
-  if (de == 64 && he == 128) k_edge_out_g<64, 128><<<io_grid(B * n), 256, EdgeIoCfg<64, 128>::OUT_BYTES, s>>>((const bf16_t*)E_h, (const uint4*)blob, G, B, n);
-  else if (de == 32 && he == 32) k_edge_out_g<32, 32><<<io_grid(B * n), 256, EdgeIoCfg<32, 32>::OUT_BYTES, s>>>((const bf16_t*)E_h, (const uint4*)blob, G, B, n);
-  else { da_set_error("da_edge_out_g: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
-  DA_CHECK_LAUNCH("da_edge_out_g");
-  return DA_OK;
-}
-int da_edge_out_finish(const float* G, const float* E_in, int de_in, const int* src, const float* skip1, const float* skip2,
-                       float* E_logits, int B, int n, int ke, void* stream) {
-  DA_CHECK_ARG(ke >= 1 && ke <= 8 && ke <= de_in, "da_edge_out_finish: ke=%d must be in 1..8 and <= input width", ke);
-  DA_CHECK_ARG(!(src && (!skip1 || !skip2)), "da_edge_out_finish: skip connection needs both scale pointers");
-  if (B == 0 || n == 0) return DA_OK;
-  const int nt = (n + 31) / 32;
-  k_edge_out_finish<<<dim3(nt, nt, B), 256, 0, (hipStream_t)stream>>>(G, E_in, de_in, src, skip1, skip2, E_logits, n, ke);
-  DA_CHECK_LAUNCH("da_edge_out_finish");
   return DA_OK;
 }
 

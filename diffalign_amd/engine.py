@@ -36,15 +36,12 @@ def use_stats_tail(n: int) -> bool:
     return STATS_TAIL and n >= STATS_TAIL_MIN_N
 
 
-Y_ON_MAIN = os.environ.get('DA_Y_ON_MAIN', '1') != '0'     # y branch on the caller's stream, node chain on the side stream (see _layers_y_on_main)
-NODE_ON_MAIN = os.environ.get('DA_NODE_ON_MAIN', '1') != '0'   # node chain on the caller's stream, y chain on the side stream (see _layers_node_on_main)
-FUSED_X_IN = os.environ.get('DA_FUSED_X_IN', '1') != '0'   # node input stage as one kernel (da_x_in) instead of two da_linear + da_x_in_finish
-TABLE_IN = os.environ.get('DA_TABLE_IN', '1') != '0'       # first edge layer reads its input from the input stage's table (da_edge_in_classes / da_edge_layer_table)
-EARLY_QKV0 = os.environ.get('DA_EARLY_QKV0', '1') != '0'   # layer 0's q/k/v and Xtoy term behind the node input path (A/B switch)
-FUSED_STEP = os.environ.get('DA_FUSED_STEP', '1') != '0'   # reverse_step draws the edge half inside the output kernel (da_edge_out_sample)
-EDGE_OUT = os.environ.get('DA_EDGE_OUT', 'tiles')   # 'tiles': da_edge_out_tiles; '2pass': da_edge_out_g + da_edge_out_finish; '1pass': da_edge_out
-SIDE_STREAM = os.environ.get('DA_SIDE_STREAM', '1') != '0'   # y_update(l) -> y_film(l+1) on a second HIP stream (see _side_stream)
-SPLIT_TAIL = os.environ.get('DA_EDGE_SPLIT', '1') != '0'   # load-balance the edge kernel's last round (da_edge_split_scratch_bytes)
+# One arrangement of everything else (round 3; the alternates' A/B numbers and bit-equality evidence are in DESIGN.md 3.4): node chain on
+# the caller's stream with the y chain and the node-feature work on two side streams (_layers_node_on_main), fused node input stage,
+# first layer from the input stage's class table, edge output as mirrored tiles with the reverse step drawn inside.  Under HIP-graph
+# capture (no side streams) the same kernels run on one stream (layer_forward).  The two attributes below are test hooks, not switches.
+TABLE_IN = True        # first edge layer reads its input rows from the input stage's table (da_edge_in_classes / da_edge_layer_table)
+SPLIT_TAIL = True      # load-balance the edge kernel's last round (da_edge_split_scratch_bytes); False: whole rows only
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
 
 
@@ -88,7 +85,7 @@ class PackedModel:
         self.in_X = [bw('mlp_in_X.0.weight'), f32(g('mlp_in_X.0.bias')), bw('mlp_in_X.2.weight'), f32(g('mlp_in_X.2.bias'))]
         # fused node input stage (da_x_in) where its widths are built
         self.x_in = (pack.x_in_blob(sd, prefix).to(dev)
-                     if FUSED_X_IN and L.lib().da_x_in_blob_bytes(_i(g('mlp_in_X.0.weight').shape[1]), _i(self.hx), _i(self.dx)) > 0 else None)
+                     if L.lib().da_x_in_blob_bytes(_i(g('mlp_in_X.0.weight').shape[1]), _i(self.hx), _i(self.dx)) > 0 else None)
         self.in_y = [f32(g('mlp_in_y.0.weight')), f32(g('mlp_in_y.0.bias')), f32(g('mlp_in_y.2.weight')), f32(g('mlp_in_y.2.bias'))]
         self.in_E = pack.edge_in_blob(sd, prefix).to(dev)
         self.out_X = [bw('mlp_out_X.0.weight'), f32(g('mlp_out_X.0.bias')), bw('mlp_out_X.2.weight'), f32(g('mlp_out_X.2.bias'))]
@@ -301,14 +298,14 @@ _SIDE = {}
 
 
 def _side_stream(dev):
-    """Second HIP stream for the latency-bound tail of the y branch (DA_SIDE_STREAM=0 turns it off).  The pooled statistics
+    """Second HIP stream for the latency-bound tail of the y branch (none under HIP-graph capture).  The pooled statistics
     of a layer's input stay on the main stream (one HBM-bound pass; the edge kernel owns every CU's registers, nothing
     overlaps with it; on a third stream, beside the node tail and the next q/k/v, it made the step 1-2 % slower).  What moves is y_update(l) -> y_film(l+1): 64 workgroups and ~15 barriers each, enqueued behind
     the edge kernel of layer l so that they run beside the node tail of layer l and the q/k/v and statistics passes of
     layer l+1; the main stream joins right before the edge kernel of layer l+1.  A second side stream carries what depends on the
     node features only: the Xtoy statistics beside q/k/v, the node input / output paths beside the edge input / output
     stages, and (helpers.posterior_sample) the node half of the reverse step.  Returns (y stream, node stream) or None."""
-    if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
@@ -324,7 +321,7 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
     events are off the critical path, provided its 1,024-thread workgroups find free CUs: da_x_post runs four row tiles per
     workgroup (150 CUs at 19,200 rows) instead of 600 single-wave workgroups that take a whole SIMD's registers each on every CU.
     Gap between two edge kernels 134 -> 115 us; steps in alternating same-box runs: 13.16 -> 13.01 ms (headline), 4.02 -> 3.91 ms
-    (B = 64, n = 140), 2.70 -> 2.65 ms (B = 100, n = 72), 7.26 -> 7.11 ms (USPTO-like).  DA_NODE_ON_MAIN=0: _layers_y_on_main.
+    (B = 64, n = 140), 2.70 -> 2.65 ms (B = 100, n = 72), 7.26 -> 7.11 ms (USPTO-like).
     `pre` = (Qm, kvf, xst, xy) of layer 0 from the input stage (model_forward)."""
     dev = Xh.device
     Qm, kvf, xst, xy = pre
@@ -377,77 +374,6 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
     return Xh, Eh, yh
 
 
-def _layers_y_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre=None, table0=None):
-    """The layer stack with three streams.  Between two edge kernels two chains run: the y branch (y_update(l) needs the Etoy
-    statistics the edge kernel of layer l leaves, then the FiLM vectors of layer l+1: ~100 us, 64 small workgroups) and the node chain
-    (merge, node tail of layer l, q/k/v of layer l+1: ~80 us).  The LONGER one, the y branch, stays on the caller's stream right
-    behind the edge kernel and in front of the next one, so that it never waits for a cross-stream event (each costs 15-30 us of
-    idle GPU when it is on the critical path); the node chain runs on a side stream, the Xtoy statistics of the next layer on a
-    third.  Every buffer is allocated on the caller's stream and stays referenced until that stream has joined its last reader.
-    `pre` = (Qm, kvf, xst, xy) of layer 0 when the input stage already produced them behind the node features (model_forward)."""
-    dev = Xh.device
-    ev_x = None                                      # q/k/v of the coming layer complete (side stream)
-    if pre is not None:
-        Qm, kvf, xst, xy = pre
-        if y_done0 is not None:
-            main.wait_event(y_done0)                 # FiLM vectors of layer 0 (y stream of the input stage)
-    else:
-        xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
-        xy = torch.empty(B, pm.dy, device=dev)
-        Qm, kvf = _qkv_buffers(pm, B, n, dev)
-        x_ready = main.record_event()
-        with torch.cuda.stream(side2):               # Xtoy statistics of layer 0's input and their x_y.lin term
-            side2.wait_event(x_ready)
-            node_stats(pm, Xh, B, n, out=xst)
-            y_pre(pm, pm.layers[0], xst, B, n, xy)
-            xs_done = side2.record_event()
-        _qkv(pm, pm.layers[0], Xh, nm, B, n, out=(Qm, kvf))
-        if y_done0 is not None:
-            main.wait_event(y_done0)                 # FiLM vectors of layer 0 (y stream of the input stage)
-        main.wait_event(xs_done)
-    keep = []
-    for li, lw in enumerate(pm.layers):
-        nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
-        tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
-        st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
-        X_next = torch.empty(B, n, pm.dx, device=dev)
-        y_next = torch.empty(B, pm.dy, device=dev)
-        film_next = film_buffers(pm, B, dev) if nxt is not None else None
-        qkv_next = _qkv_buffers(pm, B, n, dev) if nxt is not None else None
-        xst_next = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev) if nxt is not None else None
-        xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
-        if ev_x is not None:
-            main.wait_event(ev_x)
-        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None)
-        ev_edge = main.record_event()
-        with torch.cuda.stream(side):                # node chain
-            side.wait_event(ev_edge)
-            _x_post(pm, lw, newX_in, Xh, nm, B, n, out=X_next)
-            ev_xp = side.record_event()
-        if nxt is not None:
-            with torch.cuda.stream(side2):           # next layer's Xtoy statistics and their x_y.lin term beside its q/k/v
-                side2.wait_event(ev_xp)
-                node_stats(pm, X_next, B, n, out=xst_next)
-                y_pre(pm, nxt, xst_next, B, n, xy_next)
-                xs_next_done = side2.record_event()
-        with torch.cuda.stream(side):
-            if nxt is not None:
-                _qkv(pm, nxt, X_next, nm, B, n, out=qkv_next)
-                side.wait_event(xs_next_done)        # one event for the caller's stream to wait on: q/k/v and the Xtoy term
-            ev_x = side.record_event()
-        # y chain, behind the edge kernel on its own stream (xy of this layer was joined before the edge kernel through ev_x)
-        y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
-        keep.append((Xh, Eh, yh, film, Qm, kvf, xst, xy, st, newX_in, split))
-        if len(keep) > 2:
-            keep.pop(0)                              # layer l-2: main has joined the side streams of layer l-1 since
-        Xh, Eh, yh, film, xst, xy = X_next, E_next, y_next, film_next, xst_next, xy_next
-        if nxt is not None:
-            Qm, kvf = qkv_next
-    main.wait_event(ev_x)
-    del keep
-    return Xh, Eh, yh
-
-
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
                   use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None, edge_skip_uniform=False, align_src=None):
     """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
@@ -479,7 +405,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
 
     # with the three-stream layer stack, what layer 0 needs from the node features alone (q/k/v, the Xtoy statistics and their x_y.lin
     # term) follows them on their stream, beside the edge input stage; the alignment index, which only the output stage reads, goes last
-    early0 = side is not None and side2 is not None and Y_ON_MAIN and EARLY_QKV0
+    early0 = side is not None and side2 is not None
     pre = (*_qkv_buffers(pm, B, n, dev), torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev), torch.empty(B, pm.dy, device=dev)) if early0 else None
 
     def node_features():
@@ -517,7 +443,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     # one-hot symmetric inputs (every diffusion state): the first layer takes its input rows from the input stage's table through a
     # one-byte class per pair, and the hidden tensor is neither written here nor read there
     table0 = None
-    if TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None and Y_ON_MAIN:
+    if TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None:
         cls_map = torch.empty(B, n, n, dtype=torch.uint8, device=dev)
         L.check(lib.da_edge_in_classes(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags), _i(B),
                                        _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_in_classes')
@@ -549,47 +475,7 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
-        if Y_ON_MAIN and NODE_ON_MAIN and pre is not None:
-            Xh, Eh, yh = _layers_node_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre, table0=table0)
-        elif Y_ON_MAIN:
-            Xh, Eh, yh = _layers_y_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre=pre, table0=table0)
-        else:
-            # every buffer is allocated on the main stream and stays referenced until the main stream has joined the side stream
-            film, y_done = film0, y_done0
-            keep = []
-            for li, lw in enumerate(pm.layers):
-                tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
-                st = st0 if li == 0 else (tail if tail is not None else edge_stats(Eh, B, n, pm.de))
-                xst = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev)
-                xy = torch.empty(B, pm.dy, device=dev)
-                x_ready = main.record_event()            # Xh is complete: its Xtoy statistics run beside q/k/v on a stream of their own
-                with torch.cuda.stream(side2):               # (on the y stream they lengthen the chain the next edge kernel waits for: +0.12 ms/step)
-                    side2.wait_event(x_ready)
-                    node_stats(pm, Xh, B, n, out=xst)
-                    y_pre(pm, lw, xst, B, n, xy)         # ... and their x_y.lin term, the largest contraction of the y branch
-                    xs_done = side2.record_event()
-                nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
-                y_next = torch.empty(B, pm.dy, device=dev)
-                film_next = film_buffers(pm, B, dev) if nxt is not None else None
-
-                def join(ev=y_done):
-                    if ev is not None:
-                        main.wait_event(ev)              # FiLM vectors of this layer (side stream) are complete
-
-                def fork(lw=lw, y=yh, st=st, xy=xy, xs_done=xs_done, y_next=y_next, nxt=nxt, film_next=film_next):
-                    ready = main.record_event()          # behind the edge kernel: statistics of this layer's input are complete
-                    with torch.cuda.stream(side):
-                        side.wait_event(xs_done)
-                        side.wait_event(ready)
-                        y_update_film(pm, lw, nxt, y, xy, st, B, n, y_next, film_next)   # y_update(l) + FiLM vectors of layer l+1: one launch
-
-                X_next, E_next = layer_main(pm, lw, Xh, Eh, yh, nm, B, n, film=film, before_edge=join, after_edge=fork, stats_out=tail)
-                y_done = side.record_event()
-                keep.clear()                             # layer l-1's buffers: the main stream joined their reader inside layer_main
-                keep.append((Xh, yh, st, xst, xy, film))
-                Xh, Eh, yh, film = X_next, E_next, y_next, film_next
-            main.wait_event(y_done)
-            del keep
+        Xh, Eh, yh = _layers_node_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre, table0=table0)
     # ---- output stage (the node output path beside the edge output stage)
     h1 = torch.empty(R, pm.hx, device=dev)
     lin = torch.empty(R, pm.kx, device=dev)
@@ -629,17 +515,9 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                                        C.c_float(c['temp'][1]), L.ptr(c['noise_E']), L.ptr(c['seeds']),
                                        int(c['call']), L.ptr(c['orig_E']), L.ptr(c['me']), L.ptr(c['zs_E']), _i(B), _i(n), _i(pm.de), _i(pm.he),
                                        _i(pm.ke), S), 'da_edge_out_sample')
-    elif EDGE_OUT == 'tiles':
+    else:
         L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo),
                                       _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')
-    elif EDGE_OUT == '2pass':
-        G = torch.empty(B, n, n, 8, device=dev)
-        L.check(lib.da_edge_out_g(L.ptr(Eh), L.ptr(pm.out_E), L.ptr(G), _i(B), _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_out_g')
-        L.check(lib.da_edge_out_finish(L.ptr(G), L.ptr(E), _i(pm.de_in), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo), _i(B), _i(n),
-                                       _i(pm.ke), S), 'da_edge_out_finish')
-    else:
-        L.check(lib.da_edge_out(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo), _i(B),
-                                _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out')
     if xout_done is not None:
         main.wait_event(xout_done)
     if save is not None:

@@ -69,7 +69,12 @@ class GraphedTrainStep:
     the replay costs one launch.  What changes between steps lives in static device buffers: the batch (copied in before a replay),
     the positional encodings (they depend on the condition only: computed outside, eagerly) and the optimiser's step counter
     (optim.FlatAdamW(device_step=True)).  Random draws (t, the noise, dropout masks) come from torch's graph-safe device generator.
-    One graph per batch shape."""
+    One graph per batch shape.
+
+    Building the object does not train: the `warmup` eager steps (they settle allocator pools, workspaces and lazily built tables)
+    and the capture pass run on the example batch, and the weights, both moments, the device step counter and the host's `steps` are
+    put back to what they were afterwards (torch's generator state is consumed).  After N calls opt.steps == int(opt.step_dev)
+    == the count before construction + N."""
 
     def __init__(self, model, optimizer, example: PlaceHolder, warmup: int = 3, group=None):
         assert optimizer.step_dev is not None, 'GraphedTrainStep needs optim.FlatAdamW(..., device_step=True)'
@@ -79,15 +84,28 @@ class GraphedTrainStep:
         self.pos = model.get_pos_encodings(self.data)
         if self.pos is not None:
             self.pos = self.pos.clone()
+        opt = optimizer
+        bufs = [b for b in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq, opt.step_dev) if b is not None]
+        keep = [b.clone() for b in bufs]
+        keep_host = (opt.steps, set(opt._ever), dict(opt._joined))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):                          # settles allocator pools, workspaces and lazily built tables
+            for _ in range(warmup):                          # real steps on the example batch; undone below
                 model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos, update_ema=False)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = model.train_one_step(self.data, optimizer, group=group, pos_encodings=self.pos, update_ema=False)
+        for b, k in zip(bufs, keep):                         # the capture pass enqueued nothing; the warm-up steps are taken back
+            b.copy_(k)
+        opt.steps = keep_host[0]                             # (the capture pass ran FlatAdamW.step() in Python: its count too)
+        if keep_host[0] > 0 or keep_host[1]:
+            opt._ever, opt._joined = keep_host[1], keep_host[2]
+        else:
+            opt._joined = {i: 0 for i in opt._ever}          # a fresh optimiser: every trained parameter joins at step 0
+        from . import _lib as L_
+        L_.weights_epoch += 1
 
     def __call__(self, data: PlaceHolder) -> torch.Tensor:
         """One optimisation step on `data` (same shapes as the example).  Returns the (static) loss tensor of this step."""

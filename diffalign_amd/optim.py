@@ -5,7 +5,16 @@ the whole 32.7 MB gradient (distributed.allreduce_flat_gradient) and the update 
 
 A `torch.optim.Optimizer`: torch's learning-rate schedulers drive `param_groups[0]['lr']` (utils/setup.py:357), and
 `state_dict()` / `load_state_dict()` speak torch.optim.AdamW's format, so the `optimizer_state_dict` of a reference checkpoint
-(training/helpers.py:99-110, utils/setup.py:331-346) resumes here and a checkpoint written here resumes there."""
+(training/helpers.py:99-110, utils/setup.py:331-346) resumes here and a checkpoint written here resumes there.
+
+Parameters with requires_grad=False (the reference builds AdamW over the diffusion object's parameters, utils/setup.py:356, which with
+use_ema include the frozen EMA copy) stay in the parameter group -- the indices of state_dict()['param_groups'][0]['params'] are
+positions in the list the optimiser was built from, as in torch -- and are left out of the flat buffers only.
+
+One divergence from torch, documented: the kernel's bias correction uses ONE update count for every parameter.  torch counts per
+parameter, so a parameter that receives its first gradient k steps late is corrected with step - k there and with step here.  The
+saved 'step' of such a parameter is its own count (step minus the step it joined at), as torch would have saved it; on load the
+largest count becomes the shared one.  In this model every trained parameter has a gradient from the first step on."""
 from __future__ import annotations
 
 import torch
@@ -19,11 +28,12 @@ def _pad(k: int) -> int:
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, device_step=False):
-        params = [p for p in params if p.requires_grad]
-        assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), 'fp32 parameters on a HIP device'
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         assert len(self.param_groups) == 1, 'one parameter group (the reference has one)'
-        self.params = self.param_groups[0]['params']
+        self.all_params = self.param_groups[0]['params']          # torch's index space (frozen parameters included)
+        self.group_index = [j for j, p in enumerate(self.all_params) if p.requires_grad]   # flat slot i -> index in the group
+        self.params = [self.all_params[j] for j in self.group_index]
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), 'fp32 parameters on a HIP device'
         dev = self.params[0].device
         n = sum(_pad(p.numel()) for p in self.params)
         self.flat_param = torch.zeros(n, device=dev)
@@ -46,6 +56,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._active_key = None
         self._written = set()      # indices of parameters whose gradient slot holds this step's gradient
         self._ever = set()         # indices of parameters that have ever been updated with a gradient (torch keeps state for these only)
+        self._joined = {}          # slot -> value of `steps` when the parameter had its first gradient (its own count = steps - that)
 
     # the hyper-parameters live in the parameter group, where schedulers and load_state_dict change them
     lr = property(lambda self: self.param_groups[0]['lr'])
@@ -71,7 +82,9 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is not None:
                 p.grad = view
                 self._written.add(i)
-                self._ever.add(i)
+                if i not in self._ever:
+                    self._ever.add(i)
+                    self._joined[i] = self.steps
             elif i in self._written:                             # had a gradient in an earlier step, none now: no stale values
                 view.zero_()
                 self._written.discard(i)
@@ -120,16 +133,23 @@ class FlatAdamW(torch.optim.Optimizer):
                 continue                                         # torch has no entry for a parameter that never had a gradient
             k = p.numel()
             cut = lambda buf: buf[o:o + k].view_as(p).clone()
-            state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': cut(self.exp_avg), 'exp_avg_sq': cut(self.exp_avg_sq)}
+            j = self.group_index[i]
+            state[j] = {'step': torch.tensor(float(self.steps - self._joined.get(i, 0))), 'exp_avg': cut(self.exp_avg), 'exp_avg_sq': cut(self.exp_avg_sq)}
             if self.max_exp_avg_sq is not None:
-                state[i]['max_exp_avg_sq'] = cut(self.max_exp_avg_sq)
+                state[j]['max_exp_avg_sq'] = cut(self.max_exp_avg_sq)
         group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
-        group['params'] = list(range(len(self.params)))
+        group['params'] = list(range(len(self.all_params)))
         return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, state_dict):
+        """torch.optim.AdamW's format.  The saved parameter list must be this optimiser's list (same length, same order), or, for a
+        reference checkpoint written with use_ema, a superset of it whose extra entries come last (the frozen EMA copy, which has no
+        state): parameters are matched by position."""
         groups = state_dict['param_groups']
-        assert len(groups) == 1 and len(groups[0]['params']) == len(self.params), 'optimizer state of another parameter list'
+        assert len(groups) == 1 and len(groups[0]['params']) >= len(self.all_params), 'optimizer state of another parameter list'
+        saved_ids = list(groups[0]['params'])
+        extra = set(saved_ids[len(self.all_params):])
+        assert not (extra & set(state_dict['state'])), 'optimizer state of another parameter list (state for parameters this optimizer does not have)'
         for k in ('lr', 'betas', 'eps', 'weight_decay'):
             if k in groups[0]:
                 self.param_groups[0][k] = groups[0][k]
@@ -141,16 +161,19 @@ class FlatAdamW(torch.optim.Optimizer):
         for buf in (self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq):
             if buf is not None:
                 buf.zero_()
-        index = {pid: i for i, pid in enumerate(groups[0]['params'])}
-        steps, self._ever = 0, set()
+        slot_of = {j: i for i, j in enumerate(self.group_index)}
+        own = {}                                                 # slot -> that parameter's own update count
         for pid, st in state_dict['state'].items():
-            i = index[pid]
-            self._ever.add(i)
-            steps = max(steps, int(float(st['step'])))
+            j = saved_ids.index(pid)
+            assert j in slot_of, f'optimizer state for parameter {j}, which does not require a gradient here'
+            own[slot_of[j]] = int(float(st['step']))
+        steps = max(own.values(), default=0)
+        self._ever = set(own)
+        self._joined = {i: steps - c for i, c in own.items()}
         for i, p, o in self._slots():
             if i not in self._ever:
                 continue
-            st = state_dict['state'][groups[0]['params'][i]]
+            st = state_dict['state'][saved_ids[self.group_index[i]]]
             k = p.numel()
             self.exp_avg[o:o + k].copy_(st['exp_avg'].reshape(-1))
             self.exp_avg_sq[o:o + k].copy_(st['exp_avg_sq'].reshape(-1))

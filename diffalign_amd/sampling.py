@@ -111,7 +111,9 @@ class SamplingMixin:
                 pX, pE = self._guide(z_t, t_array, pX, pE, cond_free)
             if record:                                                                   # sampling.py:120-161 (plotting chains)
                 sample_chains.append((t_int, z_t.get_new_object().mask(z_t.node_mask, collapse=True)))
-                p0 = pred.get_new_object(X=torch.softmax(pred.X, -1), E=torch.softmax(pred.E, -1))
+                # the reference softmaxes the temperature-scaled log-probabilities (sampling.py:82, 122-123), not the raw logits
+                p0 = pred.get_new_object(X=torch.softmax(temps[0] * torch.log_softmax(pred.X, -1), -1),
+                                         E=torch.softmax(temps[1] * torch.log_softmax(pred.E, -1), -1))
                 p0.X[..., -1] = 0.                                         # SuNo predictions ignored (sampling.py:125-126)
                 p0.X /= p0.X.sum(-1, keepdim=True)
                 for chain, obj in ((pred_0_chains, p0), (prob_s_chains, z_t.get_new_object(X=pX, E=pE))):

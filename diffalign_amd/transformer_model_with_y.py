@@ -60,7 +60,7 @@ class _DenoiserBase(nn.Module):
 
     def supports_fused_step(self):
         """da_edge_out_sample (the reverse step's edge half inside the output kernel) is built for 7 edge classes."""
-        return self.out_dim_E == 7 and engine.EDGE_OUT == 'tiles' and engine.FUSED_STEP and not self.improved
+        return self.out_dim_E == 7 and not self.improved
 
     def _check(self, X):
         if not X.is_cuda:

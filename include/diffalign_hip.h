@@ -16,8 +16,15 @@
 extern "C" {
 #endif
 
+/* Version of this header's contracts; a binding built against another version must refuse the library (diffalign_amd/_lib.py does).
+ * 3: da_init added, da_edge_out_g / da_edge_out_finish removed.  2: da_y_film / da_y_update / da_y_update_film / da_y_pre expect the
+ * y-chain weights k-major, i.e. transposed to (in, out); da_edge_layer_stats puts its ticket word back to zero itself. */
+#define DA_ABI_VERSION 3
 int da_abi_version(void);
 const char* da_last_error(void);
+/* Per-device set-up that must not run under stream capture (today: the device address of da_edge_in_sym_static's scratch).  Call once
+ * per device, with that device current, before the first captured call.  No counterpart in the reference. */
+int da_init(void);
 
 /* ---- L0 container + masks ------------------------------------------------------------------------------------ */
 
@@ -364,14 +371,6 @@ int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void
                        const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
                        float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
                        float* zs_E, int B, int n, int de, int he, int ke, void* stream);
-/* The same output stage in two passes, each hidden edge row read once and mlp_out_E evaluated once per ordered pair
- * (da_edge_out evaluates both orientations in one pass and reads the hidden tensor twice): G (B,n,n,8) fp32 is a scratch
- * the caller owns.  da_edge_out_g: G = mlp_out_E(E_h) (transformer_model_with_y.py:672-673); da_edge_out_finish:
- * logits = sym((G + E_in[..., :ke]) * offdiag) [+ skip] (:674-704).  Bit-identical to da_edge_out. */
-int da_edge_out_g(const void* E_h, const void* blob, float* G, int B, int n, int de, int he, void* stream);
-int da_edge_out_finish(const float* G, const float* E_in, int de_in, const int* src, const float* skip1, const float* skip2,
-                       float* E_logits, int B, int n, int ke, void* stream);
-
 /* ---- extra input features of the denoiser (reference: CPU round trip at every step,
  * diffusion/diffusion_abstract.py:350-372).  The two adjacency powers and the batched symmetric eigendecomposition between
  * these calls are library routines (torch.bmm, torch.linalg.eigh on the device; diffalign_amd/extra_features.py). ---- */

@@ -69,33 +69,39 @@ class _Cond:
 
 def _stub_sample_for_condition(dense_data, n_samples, inpaint_node_idx, inpaint_edge_idx, chain_seeds):
     """Stands in for DiscreteDenoisingDiffusionRxn.sample_for_condition on the CPU: 'samples' that are a deterministic function
-    of the condition and of each chain's own counter-based noise (oracle.counter_exp_noise) -- as the real chains are."""
+    of the condition and of each chain's own counter-based noise (oracle.counter_exp_noise) -- as the real chains are.  The driver
+    hands over a batch of equal-size conditions, each row already one chain (n_samples = 1), with per-row inpainting lists."""
     from types import SimpleNamespace
     from oracle import oracle as O
-    n = dense_data.X.shape[1]
-    assert chain_seeds.shape == (n_samples,)
+    k, n = dense_data.X.shape[:2]
+    assert n_samples == 1 and chain_seeds.shape == (k,)
     qX, qE = O.counter_exp_noise(chain_seeds, 0, n, 29, 7)
     X = (1.0 / qX).argmax(-1) + dense_data.X.argmax(-1)                      # (k, n)
     E = (1.0 / qE).argmax(-1)
     E = torch.triu(E, 1); E = E + E.transpose(1, 2)
     if inpaint_node_idx is not None:
-        X[:, inpaint_node_idx[0]] = 99
+        assert len(inpaint_node_idx) == k
+        for r, idx in enumerate(inpaint_node_idx):
+            X[r, idx] = 99
     return SimpleNamespace(X=X, E=E)
 
 
 def _conditions():
     g = torch.Generator().manual_seed(3)
-    sizes = [6, 9, 4]
+    sizes = [6, 9, 4, 6, 9]
     return [_Cond(torch.nn.functional.one_hot(torch.randint(0, 29, (1, n), generator=g), 29).float(), torch.zeros(1, n, n, 7)) for n in sizes]
 
 
-def _cond_worker(rank, world, port, out, n_cond, n_samples):
+INPAINT = [[0], [1, 2], [], [3], []]
+
+
+def _cond_worker(rank, world, port, out, n_cond, n_samples, balance):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from diffalign_amd.distributed import sample_conditions_sharded
     res = sample_conditions_sharded(_conditions()[:n_cond], n_samples, _stub_sample_for_condition, seed=11,
-                                    inpaint_node_idx=[[0], [1, 2], []][:n_cond])
+                                    inpaint_node_idx=INPAINT[:n_cond], balance=balance, max_pairs=4 * 81)
     if rank == 0:
         torch.save(res, out)
     else:
@@ -105,19 +111,48 @@ def _cond_worker(rank, world, port, out, n_cond, n_samples):
 
 
 def test_two_rank_condition_sampling_equals_single_rank(tmp_path):
-    """BASELINE configs[2] driver: (condition, sample) units cut over 2 ranks mid-condition, per-chain seeds, ragged condition
-    sizes padded for the gather -> the same samples as one rank; and fewer chains than ranks (one rank's shard is empty)."""
+    """BASELINE configs[2] driver: (condition, sample) units cut over 2 ranks mid-condition (equal counts, or by cost ~ n^2 with the
+    large conditions first), equal-size conditions run as one batch, per-chain seeds, ragged condition sizes padded for the gather
+    -> the same samples as one rank in condition-major order whatever the partition; and fewer chains than ranks (an empty shard)."""
     from diffalign_amd.distributed import sample_conditions_sharded
-    for k, (n_cond, n_samples) in enumerate([(3, 5), (1, 1)]):
+    sizes = [6, 9, 4, 6, 9]
+    k = 0
+    for n_cond, n_samples in [(5, 3), (3, 5), (1, 1)]:
         ref = sample_conditions_sharded(_conditions()[:n_cond], n_samples, _stub_sample_for_condition, seed=11,
-                                        inpaint_node_idx=[[0], [1, 2], []][:n_cond])
-        assert ref[0].shape == (n_cond * n_samples, max([6, 9, 4][:n_cond])) and ref[0].dtype == torch.uint8
-        out = str(tmp_path / f'c{k}.pt')
-        port = 33500 + (os.getpid() % 2000) + k
-        mp.spawn(_cond_worker, args=(2, port, out, n_cond, n_samples), nprocs=2, join=True)
-        X, E = torch.load(out)
-        assert torch.equal(X, ref[0]) and torch.equal(E, ref[1])
+                                        inpaint_node_idx=INPAINT[:n_cond], balance=False)
+        assert ref[0].shape == (n_cond * n_samples, max(sizes[:n_cond])) and ref[0].dtype == torch.uint8
+        one = sample_conditions_sharded(_conditions()[:n_cond], n_samples, _stub_sample_for_condition, seed=11,
+                                        inpaint_node_idx=INPAINT[:n_cond], balance=True)
+        assert torch.equal(one[0], ref[0]) and torch.equal(one[1], ref[1])          # one rank, size-ordered batches: same chains
+        for balance in (False, True):
+            out = str(tmp_path / f'c{k}.pt')
+            port = 33500 + (os.getpid() % 2000) + k
+            k += 1
+            mp.spawn(_cond_worker, args=(2, port, out, n_cond, n_samples, balance), nprocs=2, join=True)
+            X, E = torch.load(out)
+            assert torch.equal(X, ref[0]) and torch.equal(E, ref[1])
     assert (ref[0][0, 0] == 99)
+
+
+def test_cost_balanced_partition():
+    """plan_condition_shards: every unit exactly once; with skewed sizes the cost-balanced cuts keep the largest shard's cost well
+    below what equal-count condition-major cuts give; equal sizes stay adjacent (they run as one batch)."""
+    from diffalign_amd.distributed import plan_condition_shards, balanced_cuts, unit_cost
+    sizes = [300, 40, 40, 72, 72, 72, 150, 40]
+    for world in (1, 2, 3, 8):
+        for balance in (False, True):
+            plan = plan_condition_shards(sizes, 7, world, balance)
+            flat = [u for p in plan for u in p]
+            assert sorted(flat) == [(c, s) for c in range(len(sizes)) for s in range(7)] and len(plan) == world
+    cost = lambda p: sum(unit_cost(sizes[c]) for c, _ in p)
+    bal, eq = plan_condition_shards(sizes, 7, 4, True), plan_condition_shards(sizes, 7, 4, False)
+    assert max(map(cost, bal)) < 0.6 * max(map(cost, eq))
+    assert max(map(cost, bal)) < 1.35 * sum(map(cost, bal)) / 4
+    for p in bal:                                              # sizes are non-increasing inside a shard
+        ns = [sizes[c] for c, _ in p]
+        assert ns == sorted(ns, reverse=True)
+    assert balanced_cuts([], 3) == [(0, 0), (0, 0), (0, 0)]
+    assert balanced_cuts([1.0], 2) in ([(0, 1), (1, 1)], [(0, 0), (0, 1)])
 
 
 def _grad_worker(rank, world, port, out):

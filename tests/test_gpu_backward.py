@@ -343,6 +343,60 @@ def test_adamw_checkpoint_exchange_with_torch_and_scheduler(device_step):
     assert torch.equal(c[dead].detach(), ps[dead])
 
 
+def test_adamw_frozen_parameters_keep_torchs_index_space():
+    """The reference builds AdamW over a parameter list that can contain frozen parameters (with use_ema: the EMA copy, utils/setup.py:356).
+    They stay in the parameter group's index space, out of the flat buffers: a torch-written state dict of such a module loads here and
+    one written here loads in torch; a reference list that is a superset (extra frozen entries last) loads too; a parameter that joins
+    late saves its own update count."""
+    from diffalign_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(4)
+    shapes = [(5, 3), (4,), (6, 2), (3,), (2, 2)]
+    frozen = {1, 4}
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=True)
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(6)]
+    mk = lambda dev: [torch.nn.Parameter(p.clone().to(dev), requires_grad=i not in frozen) for i, p in enumerate(ps)]
+
+    def run(opt, params, lo, hi, skip=()):
+        for t in range(lo, hi):
+            opt.zero_grad()
+            for i, p in enumerate(params):
+                if p.requires_grad and not (i in skip and t == 0):
+                    p.grad = grads[t][i].to(p.device).clone()
+            if isinstance(opt, FlatAdamW):
+                opt.gather()
+            opt.step()
+
+    ref = mk('cpu'); o_ref = torch.optim.AdamW(ref, **kw); run(o_ref, ref, 0, 6)
+    a = mk('cpu'); o_a = torch.optim.AdamW(a, **kw); run(o_a, a, 0, 3)
+    sd_a = o_a.state_dict()
+    assert sorted(sd_a['state']) == [0, 2, 3] and sd_a['param_groups'][0]['params'] == [0, 1, 2, 3, 4]
+    b = [torch.nn.Parameter(p.detach().clone().to(D), requires_grad=p.requires_grad) for p in a]
+    o_b = FlatAdamW(b, **kw)
+    assert len(o_b.params) == 3 and o_b.group_index == [0, 2, 3]
+    o_b.load_state_dict(sd_a)
+    run(o_b, b, 3, 6)
+    sd_b = o_b.state_dict()
+    assert sorted(sd_b['state']) == [0, 2, 3] and sd_b['param_groups'][0]['params'] == [0, 1, 2, 3, 4]
+    c = [torch.nn.Parameter(p.detach().cpu().clone(), requires_grad=p.requires_grad) for p in b]
+    o_c = torch.optim.AdamW(c, **kw)
+    o_c.load_state_dict({'state': {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd_b['state'].items()},
+                         'param_groups': sd_b['param_groups']})                      # torch's own group-size check passes
+    for r, m in zip(ref, c):
+        assert (m.detach() - r.detach()).abs().max() <= 2e-6
+    # a reference checkpoint whose list has extra frozen parameters at the end (the EMA copy): matched by position
+    sup = {'state': sd_a['state'], 'param_groups': [dict(sd_a['param_groups'][0], params=list(range(9)))]}
+    o_d = FlatAdamW([torch.nn.Parameter(p.detach().clone().to(D), requires_grad=p.requires_grad) for p in a], **kw)
+    o_d.load_state_dict(sup)
+    assert o_d.steps == 3 and torch.equal(o_d.exp_avg, o_b.exp_avg * 0 + o_d.exp_avg)
+    with pytest.raises(AssertionError):
+        o_d.load_state_dict({'state': {7: sd_a['state'][0]}, 'param_groups': sup['param_groups']})
+    # a parameter whose first gradient comes one step late saves its own count, as torch does
+    e = mk(D); o_e = FlatAdamW(e, **kw); run(o_e, e, 0, 3, skip={2})
+    steps = {k: float(v['step']) for k, v in o_e.state_dict()['state'].items()}
+    assert steps == {0: 3.0, 2: 2.0, 3: 3.0}
+
+
 def test_optimisation_steps_reduce_the_loss_and_refresh_the_inference_weights():
     """train_one_step x 8 on one fixed batch (ce): the loss falls; with dropout > 0 the step stays finite; the fused bf16
     inference path re-packs the updated weights (its loss follows the trained fp32 one)."""
@@ -396,10 +450,15 @@ def test_device_step_adamw_and_graphed_training_step():
         model.eval(); l0 = probe(); model.train()
     opt = FlatAdamW(model.model.parameters(), lr=2e-3, device_step=True)
     torch.manual_seed(1)
+    w_before = opt.flat_param.clone()
     gstep = GraphedTrainStep(model, opt, data, warmup=2)
     n0 = int(opt.step_dev)
+    # building the graph does not train: weights, moments and both step counters are what they were (warm-up steps taken back)
+    assert n0 == 0 and opt.steps == 0 and torch.equal(opt.flat_param, w_before) and float(opt.exp_avg.abs().max()) == 0.0
     losses = [float(gstep(data)) for _ in range(12)]
     assert int(opt.step_dev) == n0 + 12 and all(math.isfinite(l) for l in losses)
+    assert opt.steps == int(opt.step_dev)                                            # what state_dict() saves == what the kernel used
+    assert all(float(v['step']) == 12.0 for v in opt.state_dict()['state'].values())
     with torch.no_grad():
         model.eval(); l1 = probe()
     assert l1 < 0.8 * l0, (l0, l1)

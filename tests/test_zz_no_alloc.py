@@ -38,6 +38,22 @@ def test_static_scratch_entry_point_matches(dims):
         assert torch.cuda.memory_allocated() == before
         assert torch.equal(got, want), (call, int((got != want).sum()))
         assert scratch[:2 * B].cpu().tolist() == [1, 0] + [1] * (B - 2) + [1, 0] + [1] * (B - 2)
+    # under stream capture (what the entry point is for): the scratch address was resolved by da_init() when the library was loaded, so the
+    # captured call only enqueues memsets and kernels; the replayed graph writes the same bits
+    cap = torch.full_like(want, 5.0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            L.check(lib.da_edge_in_sym_static(L.ptr(E_d), _i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(cap), _i(B), _i(n), _i(hd['de']), _i(he),
+                                              L.stream()), 'da_edge_in_sym_static (captured)')
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        cap.fill_(5.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, want)
     # sizes beyond the static array are refused with a clear error, nothing is launched
     rc = lib.da_edge_in_sym_static(L.ptr(E_d), _i(KE), L.ptr(nm_d), L.ptr(pm.in_E), L.ptr(got), _i(4097), _i(n), _i(hd['de']), _i(he), L.stream())
     assert rc != 0 and b'4096' in lib.da_last_error()

@@ -4,8 +4,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_bench
 mkdir -p $OUT
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1 || { echo "FETCH pass failed"; tail -3 $OUT/fetch.log; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1 || { echo "WRITE pass failed"; tail -3 $OUT/write.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-loop > $OUT/fetch.log 2>&1 || { echo "FETCH pass failed"; tail -3 $OUT/fetch.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-loop > $OUT/write.log 2>&1 || { echo "WRITE pass failed"; tail -3 $OUT/write.log; exit 1; }
 python3 - <<'PY'
 import csv, glob, collections
 for name in ('fetch', 'write'):
