@@ -17,7 +17,26 @@ A, Lap, vw, vp = XF._adjacency(E, nm8, mf.consts(D)[1], True)
 pn = torch.randn(B, n, device=D)
 out = torch.zeros(B, 6, dtype=torch.float64, device=D)
 nc = torch.empty(B, device=D); ev5 = torch.empty(B, 5, device=D); nl = torch.empty(B, n, device=D); v2 = torch.empty(B, n, 2, device=D)
-for _ in range(2):
+if len(sys.argv) > 1 and sys.argv[1] == 'cached':      # second call of a chain: the fixed block comes back from the cache
+    from diffalign_amd import graph
+    from diffalign_amd.placeholder import PlaceHolder
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    masks = graph.get_node_masks(data, list(ATOMS), ['none', 'SINGLE', 'DOUBLE', 'TRIPLE', 'mol', 'within', 'across'], 'product_and_sn', 'product_and_sn')
+    cache = XF.EigCache.from_free_masks(masks[1], data.node_mask)
+    for _ in range(3):
+        Lc = Lap.clone()
+        L.check(L.lib().da_extra_eigen_solve_cached(L.ptr(Lc), L.ptr(nm8), L.ptr(pn), L.ptr(nc), L.ptr(ev5), L.ptr(nl), L.ptr(v2), L.ptr(out), C.c_int(B), C.c_int(n),
+                                                    L.ptr(cache.fixed_from), L.ptr(cache.state), L.ptr(cache.store), C.c_int(cache.mmax), L.stream()), 'x')
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    Lcs = [Lap.clone() for _ in range(5)]
+    ev0.record()
+    for Lc in Lcs:
+        L.check(L.lib().da_extra_eigen_solve_cached(L.ptr(Lc), L.ptr(nm8), L.ptr(pn), L.ptr(nc), L.ptr(ev5), L.ptr(nl), L.ptr(v2), L.ptr(out), C.c_int(B), C.c_int(n),
+                                                    L.ptr(cache.fixed_from), L.ptr(cache.state), L.ptr(cache.store), C.c_int(cache.mmax), L.stream()), 'x')
+    ev1.record(); torch.cuda.synchronize()
+    print('cached call: %.3f ms per launch; states' % (ev0.elapsed_time(ev1) / 5), cache.state.unique().tolist())
+for _ in range(0 if (len(sys.argv) > 1 and sys.argv[1] == 'cached') else 2):
     Lc = Lap.clone()
     L.check(L.lib().da_extra_eigen_solve(L.ptr(Lc), L.ptr(nm8), L.ptr(pn), L.ptr(nc), L.ptr(ev5), L.ptr(nl), L.ptr(v2), L.ptr(out), C.c_int(B), C.c_int(n), L.stream()), 'x')
 torch.cuda.synchronize()
