@@ -13,6 +13,8 @@
 // vectors are one basis among many, as the reference's LAPACK vectors are: eigenvalue features are comparable, the
 // eigenvector features only through basis-independent properties (tests/golden/common.py:check_extra).
 #include <atomic>
+#include <type_traits>
+#include <cstdlib>
 #include "common.h"
 
 // LDS of k_extra_eig_solve in doubles, without the triangle: u, p, d, e, h (5n), eigenvectors (3n), solve work (9n), reductions (64),
@@ -153,6 +155,15 @@ __device__ void tri_solve(const double* d, const double* e, int lo, int hi, doub
   }
 }
 
+// Diagnostic build only (EXP_EIG_STAMP): cycles of the Householder step's six phases, summed over the steps of graph 0 by its thread 0
+#ifdef EXP_EIG_STAMP
+__device__ long long g_eig_phase[8];
+extern "C" int da_debug_read_eig_phases(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_eig_phase), sizeof(long long) * 8); }
+#define EIG_PH(i) { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = __builtin_readcyclecounter(); g_eig_phase[i] += t_ - ph_t; ph_t = t_; } }
+#else
+#define EIG_PH(i)
+#endif
+
 struct EigLds {
   double *u, *p, *d, *e, *h, *y, *w, *red, *lam, *pp, *tri;
   int *iu, *seg, *cnt, *misc;
@@ -172,6 +183,9 @@ __device__ __forceinline__ void house_step(const M& Mx, double* __restrict__ Agl
   double* s_part = S.red + pb * 32;                   // [2][16] per-wave partials of this step (double buffered over steps)
   int* s_cnt = S.cnt + pb * 32;                       // [2][16] per-wave counts of the two compactions
   first_u = k;
+#ifdef EXP_EIG_STAMP
+  long long ph_t = __builtin_readcyclecounter();
+#endif
   // (a) row k: u = A[k][0:k], sum of squares left of the sub-diagonal, the index set U (u_{k-1} = f - g is never zero)
   const double x0 = tid < k ? Mx.at(k, tid) : 0.0;
   const bool inU = tid < k && (x0 != 0.0 || tid == k - 1);
@@ -183,6 +197,7 @@ __device__ __forceinline__ void house_step(const M& Mx, double* __restrict__ Agl
   if (tid == 0) S.d[k] = Mx.at(k, k);                 // final: no later step touches row k
   if (tid == k - 1) S.lam[pb] = x0;                   // f, for everyone (its owner overwrites the entry itself with f - g below)
   __syncthreads();                                                                // (1)
+  EIG_PH(0)
   double off2 = 0.0;
 #pragma unroll
   for (int w = 0; w < EIG_NWV; ++w) off2 += s_part[w];
@@ -206,27 +221,35 @@ __device__ __forceinline__ void house_step(const M& Mx, double* __restrict__ Agl
     if (M::kLds) Mx.at(k, tid) = xk;
   }
   __syncthreads();                                                                // (2)
+  EIG_PH(1)
   first_u = S.iu[0];
-  // (b) h p = A u:  (A u)_j = sum_{i in U} A(i,j) u_i, one thread per column j and row class; partial sums meet in s_pp[class][column]
-  const int CW = (k + 63) & ~63;                      // columns rounded up to whole waves (k <= EIG_THREADS)
-  const int RC = EIG_THREADS / CW;
+  // (b) h p = A u:  (A u)_j = sum_{i in U} A(i,j) u_i, one thread per column j and row class (as many classes as the threads allow: a
+  // thread's share is a chain of dependent LDS round trips); partial sums meet in s_pp[class][column].  U = all rows (a dense
+  // component, e.g. what a random-weight denoiser leaves): no index list in the way.
+  const int CW = k;                                   // k <= EIG_THREADS
+  const int RC = min(16, EIG_THREADS / CW);
   {
     const int j = tid % CW, rc = tid / CW;
-    if (rc < RC && j < k) {
+    if (rc < RC) {
       double acc[4] = {0, 0, 0, 0};
-      int ii = rc;
-      for (; ii + 7 * RC < nU; ii += 8 * RC) {
-        double v[8]; int ix[8];
+      auto walk = [&](auto dense) {
+        auto row = [&](int ii) { return decltype(dense)::value ? ii : S.iu[ii]; };
+        int ii = rc;
+        for (; ii + 7 * RC < nU; ii += 8 * RC) {
+          double v[8]; int ix[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { ix[q] = S.iu[ii + q * RC]; v[q] = Mx.sym(ix[q], j); }
+          for (int q = 0; q < 8; ++q) { ix[q] = row(ii + q * RC); v[q] = Mx.sym(ix[q], j); }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q & 3] = fma(v[q], S.u[ix[q]], acc[q & 3]);
-      }
-      for (; ii < nU; ii += RC) { const int i = S.iu[ii]; acc[0] = fma(Mx.sym(i, j), S.u[i], acc[0]); }
+          for (int q = 0; q < 8; ++q) acc[q & 3] = fma(v[q], S.u[ix[q]], acc[q & 3]);
+        }
+        for (; ii < nU; ii += RC) { const int i = row(ii); acc[0] = fma(Mx.sym(i, j), S.u[i], acc[0]); }
+      };
+      if (nU == k) walk(std::true_type{}); else walk(std::false_type{});
       S.pp[rc * CW + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
   }
   __syncthreads();                                                                // (3)
+  EIG_PH(2)
   double pj = 0.0;
   if (tid < k) {
     for (int rc = 0; rc < RC; ++rc) pj += S.pp[rc * CW + tid];
@@ -238,6 +261,7 @@ __device__ __forceinline__ void house_step(const M& Mx, double* __restrict__ Agl
   const unsigned long long mT = __ballot(inT);
   if (lane == 0) { s_part[16 + wave] = kp; s_cnt[16 + wave] = __popcll(mT); }
   __syncthreads();                                                                // (4)
+  EIG_PH(3)
   double upu = 0.0;
   int offT = 0, nT = 0;
 #pragma unroll
@@ -245,34 +269,44 @@ __device__ __forceinline__ void house_step(const M& Mx, double* __restrict__ Agl
   if (inT) S.iu[offT + __popcll(mT & ((1ull << lane) - 1ull))] = tid;     // (the list of U is dead: every reader passed barrier 3)
   const double invh = 1.0 / h;
   const double K = upu * invh * invh * 0.5;           // u^T p / (2h) with p = (A u) / h
+  if (tid < k) S.p[tid] = fma(pj, invh, -(K * xk));   // q = p / h - K u, once per entry (s_p's only reader before this was its owner)
   __syncthreads();                                                                // (5)
-  // (c) A -= u q^T + q u^T on the lower triangle of T x T, q = p / h - K u formed on the fly
-  const int CT = (nT + 63) & ~63;
-  const int RT = EIG_THREADS / CT;
+  EIG_PH(4)
+  // (c) A -= u q^T + q u^T on the lower triangle of T x T (q in s_p).  A thread owns a column and a class of rows; the lanes of
+  // a wave walk the SAME rows (row i of the triangle is contiguous in j: conflict-free, u_i and q_i are broadcasts) and sit out
+  // the rows above their column's diagonal.
+  const int CT = nT;
+  const int RT = nT > 0 ? min(16, EIG_THREADS / CT) : 1;
   {
-    const int jj = tid % CT, rc = tid / CT;
-    if (rc < RT && jj < nT) {
-      const int j = S.iu[jj];
-      const double uj = S.u[j], qj = fma(S.p[j], invh, -(K * uj));
-      int ii = jj + rc;
-      for (; ii + 7 * RT < nT; ii += 8 * RT) {
-        double v[8]; int ix[8];
+    const int jj = nT > 0 ? tid % CT : 0, rc = nT > 0 ? tid / CT : RT;
+    if (rc < RT) {
+      auto walk = [&](auto dense) {
+        auto row = [&](int ii) { return decltype(dense)::value ? ii : S.iu[ii]; };
+        const int j = row(jj);
+        const double uj = S.u[j], qj = S.p[j];
+        int ii = rc + ((jj - rc + RT - 1) / RT) * RT;            // first row of this class at or below the diagonal (jj >= rc: else rc)
+        if (jj < rc) ii = rc;
+        for (; ii + 3 * RT < nT; ii += 4 * RT) {
+          double v[4]; int ix[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { ix[q] = S.iu[ii + q * RT]; v[q] = Mx.at(ix[q], j); }
+          for (int q = 0; q < 4; ++q) { ix[q] = row(ii + q * RT); v[q] = Mx.at(ix[q], j); }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const double ui = S.u[ix[q]], qi = fma(S.p[ix[q]], invh, -(K * ui));
-          Mx.at(ix[q], j) = v[q] - fma(qj, ui, qi * uj);
+          for (int q = 0; q < 4; ++q) {
+            const double ui = S.u[ix[q]], qi = S.p[ix[q]];
+            Mx.at(ix[q], j) = v[q] - fma(qj, ui, qi * uj);
+          }
         }
-      }
-      for (; ii < nT; ii += RT) {
-        const int i = S.iu[ii];
-        const double ui = S.u[i], qi = fma(S.p[i], invh, -(K * ui));
-        Mx.at(i, j) = Mx.at(i, j) - fma(qj, ui, qi * uj);
-      }
+        for (; ii < nT; ii += RT) {
+          const int i = row(ii);
+          const double ui = S.u[i], qi = S.p[i];
+          Mx.at(i, j) = Mx.at(i, j) - fma(qj, ui, qi * uj);
+        }
+      };
+      if (nT == k) walk(std::true_type{}); else walk(std::false_type{});
     }
   }
   __syncthreads();                                                                // (6) this step's stores before the next row is read
+  EIG_PH(5)
 }
 
 // Applies the reflectors of rows s_rows[r0 .. r1) (ascending) to the vector y, one wave: lane l holds entries l, l + 64, ... in
@@ -729,12 +763,17 @@ int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("da_extra_eigen_solve: no current HIP device"); return DA_ERR_HIP; }
   if (!attr_set[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_extra_eig_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_extra_eig_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_extra_eig_solve<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) { da_set_error("da_extra_eigen_solve: cannot reserve LDS: %s", hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set[dev].store(true, std::memory_order_release);
   }
   // a step of the reduction is a chain of barrier-separated phases over at most n entries: 8 waves serve n <= 512 with cheaper barriers
-  if (n <= 512)
+  static const int force_threads = [] { const char* e = getenv("DA_EIG_THREADS"); return e ? atoi(e) : 0; }();   // A/B hook
+  if (force_threads == 256 && n <= 256)
+    k_extra_eig_solve<256><<<B, 256, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
+                                                                 fixed_from, cache_state, cache, mmax, k_lds);
+  else if (n <= 512 && force_threads != 1024)
     k_extra_eig_solve<512><<<B, 512, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
                                                                  fixed_from, cache_state, cache, mmax, k_lds);
   else
