@@ -64,6 +64,12 @@ struct EdgeCfg {
                        P_BF2 = 2 * DX + 2 * DE + DFF, P_LN2G = 2 * DX + 3 * DE + DFF, P_LN2B = 2 * DX + 4 * DE + DFF,
                        N_PAR = 2 * DX + 5 * DE + DFF;
   static constexpr size_t BLOB_BYTES = (size_t)N_FR * 1024 + (size_t)N_PAR * 4;
+#ifdef EXP_NOEPI
+  static constexpr size_t LDS_SKIP = (size_t)(F1_FR + F2_FR) * 1024;      // timing experiment: the FFN fragments stay out of LDS
+#else
+  static constexpr size_t LDS_SKIP = 0;
+#endif
+  static constexpr size_t LDS_BLOB_BYTES = BLOB_BYTES - LDS_SKIP;
   static constexpr size_t STATE_BYTES_PER_WAVE = (size_t)NCB * 3 * 64 * 4;
 };
 
@@ -325,18 +331,18 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sW = reinterpret_cast<uint4*>(smem);
   {
-    const int n16 = (int)(C::BLOB_BYTES / 16);
-    for (int t = threadIdx.x; t < n16; t += NTHREADS) sW[t] = a.blob[t];
+    const int n16 = (int)(C::LDS_BLOB_BYTES / 16), cut = (C::W1_FR + C::WO_FR) * 64;
+    for (int t = threadIdx.x; t < n16; t += NTHREADS) sW[t] = a.blob[(C::LDS_SKIP && t >= cut) ? t + (int)(C::LDS_SKIP / 16) : t];
   }
   __syncthreads();
   const uint4* sW1 = sW;
   const uint4* sWO = sW1 + C::W1_FR * 64;
   const uint4* sF1 = sWO + C::WO_FR * 64;
   const uint4* sF2 = sF1 + C::F1_FR * 64;
-  const float* sP = reinterpret_cast<const float*>(sF2 + C::F2_FR * 64);
-  unsigned* sB1 = reinterpret_cast<unsigned*>(smem + C::BLOB_BYTES);          // [NCB][64] e_mul bias as a B-operand dword
-  float* sQF = reinterpret_cast<float*>(smem + C::BLOB_BYTES + C::NCB * 256) + (threadIdx.x >> 6) * (2 * DX + DE);
-  const uint4* sTab = reinterpret_cast<const uint4*>(smem + C::BLOB_BYTES + C::NCB * 256 + (NTHREADS / 64) * (2 * DX + DE) * 4);   // [tab_rows][DE / 8]
+  const float* sP = reinterpret_cast<const float*>(C::LDS_SKIP ? sF1 : sF2 + C::F2_FR * 64);
+  unsigned* sB1 = reinterpret_cast<unsigned*>(smem + C::LDS_BLOB_BYTES);          // [NCB][64] e_mul bias as a B-operand dword
+  float* sQF = reinterpret_cast<float*>(smem + C::LDS_BLOB_BYTES + C::NCB * 256) + (threadIdx.x >> 6) * (2 * DX + DE);
+  const uint4* sTab = reinterpret_cast<const uint4*>(smem + C::LDS_BLOB_BYTES + C::NCB * 256 + (NTHREADS / 64) * (2 * DX + DE) * 4);   // [tab_rows][DE / 8]
   if (TAB) {
     uint4* wt = const_cast<uint4*>(sTab);
     for (int t = threadIdx.x; t < a.tab_rows * (DE / 8); t += NTHREADS) wt[t] = a.tab[t];
@@ -557,6 +563,24 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         }
 #endif
       }
+#ifdef EXP_NOEPI
+      // timing experiment (split-epilogue proposal): kernel 1 would end here, storing E + newE as bf16; LN1 / FFN / LN2 move to a second kernel
+#pragma unroll
+      for (int u = 0; u < C::KS1; ++u) {
+        const int mt = u >> 1;
+        unsigned d[4];
+#pragma unroll
+        for (int gg2 = 0; gg2 < 2; ++gg2) {
+          const int g = 2 * (u & 1) + gg2;
+          d[2 * gg2 + 0] = pack_bf16(acc2[mt][4 * g + 0], acc2[mt][4 * g + 1]);
+          d[2 * gg2 + 1] = pack_bf16(acc2[mt][4 * g + 2], acc2[mt][4 * g + 3]);
+        }
+        uint4 st = {d[0], d[1], d[2], d[3]};
+        row16_to_corder(st);
+        if (jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
+      }
+      if (sum == 123.456f) Orow[0] = 0;
+#else
       const float mean1 = xhalf_sum(sum) * (1.f / DE);
       float vs = 0.f;
 #pragma unroll
@@ -644,6 +668,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
         if (jvalid) *reinterpret_cast<uint4*>(Orow + (size_t)jl * DE + 16 * u + 8 * h) = st;
 #endif
       }
+#endif
       STAMP(5)   // LN2 + store
     }
     // ---- end of the unit: merge the two lane halves' softmax states; a whole row writes the x_out input, a run of a
@@ -793,11 +818,11 @@ static int launch_edge_nt(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DA_MAX_DEVICES) { da_set_error("edge layer: no current HIP device"); return DA_ERR_HIP; }
   if (!attr_set[dev].load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES));
     if (e != hipSuccess) { da_set_error("edge layer: cannot reserve %zu B of LDS: %s", C::BLOB_BYTES, hipGetErrorString(e)); return DA_ERR_HIP; }
     attr_set[dev].store(true, std::memory_order_release);
   }
-  kern<<<grid_blocks, NT_, C::BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES, s>>>(a);
+  kern<<<grid_blocks, NT_, C::LDS_BLOB_BYTES + C::NCB * 256 + (NT_ / 64) * (2 * DX + DE) * 4 + TAB_BYTES, s>>>(a);
   return DA_OK;
 }
 // Tuning knobs of the launch (-1 = choose automatically).  Read from the environment once (DA_EDGE_THREADS, DA_EDGE_SKEW,
@@ -816,13 +841,20 @@ static EdgeTuning& edge_tuning() {
   }();
   return t;
 }
+#ifdef EXP_NT768
+static int edge_threads() { return 768; }
+#else
 static int edge_threads() { return edge_tuning().threads; }
+#endif
 template <int DE, int DX, int DFF>
 static int launch_edge(const EdgeLayerArgs& a, int grid_blocks, hipStream_t s) {
   if (a.cls != nullptr) {
     if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512, true>(a, grid_blocks, s);
     return launch_edge_nt<DE, DX, DFF, 256, true>(a, grid_blocks, s);
   }
+#ifdef EXP_NT768
+  return launch_edge_nt<DE, DX, DFF, 768>(a, grid_blocks, s);   // timing experiment: three waves per SIMD (needs EXP_NOEPI for the LDS)
+#endif
   if (edge_threads() == 512) return launch_edge_nt<DE, DX, DFF, 512>(a, grid_blocks, s);
   return launch_edge_nt<DE, DX, DFF, 256>(a, grid_blocks, s);
 }
