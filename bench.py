@@ -118,12 +118,16 @@ def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None)
     cfg = make_cfg(FULL, T=500)
     cfg.train.loss = args.train_loss
     model = DiscreteDenoisingDiffusion(cfg, make_info(), device=dev).train()
+    model.model.train_precision = args.train_precision
     true = S.make_reaction_batch(B, n, seed=1 + rank, P=None)
     data = PlaceHolder(**{k: v.to(dev) for k, v in true.items()})
-    opt = FlatAdamW(model.model.parameters(), lr=2e-4, weight_decay=1e-12, amsgrad=True, device_step=args.graph)
+    # the whole step as one HIP graph (eager is launch-bound: ~1,900 launches a step); with more than one rank only on request, since the
+    # gradient all-reduce would then be captured too
+    train_graph = args.graph == 'on' or (args.graph == 'auto' and world == 1)
+    opt = FlatAdamW(model.model.parameters(), lr=2e-4, weight_decay=1e-12, amsgrad=True, device_step=train_graph)
     group = None
     step_fn = lambda: model.train_one_step(data, opt, group=group)
-    if args.graph:                                            # the whole step replayed as one HIP graph (diffalign_amd/graphs.py)
+    if train_graph:                                    # the whole step replayed as one HIP graph (diffalign_amd/graphs.py)
         from diffalign_amd.graphs import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, data, group=group)
         step_fn = lambda: gstep(data)
@@ -149,24 +153,21 @@ def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if not emit:
-        return {'train_ms_per_step': dt / steps * 1e3, 'train_workload': f'B={B}, n={n}, loss {args.train_loss}, {TRAIN_PRECISION} forward/backward, '
+        return {'train_ms_per_step': dt / steps * 1e3, 'train_workload': f'B={B}, n={n}, loss {args.train_loss}, {args.train_precision} per-pair tensors (fp32 master weights), '
                                                                           f'AdamW(amsgrad); {steps} steps', 'train_graphs_per_s': B * steps / dt}
     if rank == 0:
         print(json.dumps({'metric': 'training graphs/sec per node (align_absorbing, data parallel)', 'value': B * steps * world / dt,
                           'unit': 'graphs/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3,
-                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.train_precision == 'bf16' else 'f32', 'data': 'synthetic',
                           'config': {'workload': f'NOT the headline -- BASELINE.json configs[3]: align_absorbing training step, loss {args.train_loss}, '
                                                  f'batch {B}/GPU padded to n={n} (USPTO-like sizes), dropout 0.2, AdamW(amsgrad), extra features and '
                                                  'Laplacian position encodings computed on the device inside the step' , 'global_batch': B * world,
-                                     'parallelism': f'dp{world} (one flat-gradient all-reduce per step)', 'hip_graph': bool(args.graph)},
+                                     'parallelism': f'dp{world} (one flat-gradient all-reduce per step)', 'hip_graph': train_graph},
                           'loss_first_last': [float(losses[0]), float(losses[-1])],
                           'peak_hbm_GB': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-TRAIN_PRECISION = 'fp32'
 
 
 def loop_object(args, model, step, z_t, data, masks, dev):
@@ -237,12 +238,17 @@ def main():
     ap.add_argument('--train-batch', type=int, default=16)
     ap.add_argument('--train-nodes', type=int, default=140)
     ap.add_argument('--train-loss', choices=['ce', 'vb', 'vbce'], default='vb')
+    ap.add_argument('--train-precision', choices=['fp32', 'bf16'], default='bf16',
+                    help="'bf16' (default): mixed precision for the per-pair tensors, as the reference's fp16 autocast; 'fp32': everything fp32")
     ap.add_argument('--force-dist', action='store_true',
                     help='with --gpus 1: create a world-size-1 nccl (RCCL) process group anyway and take the multi-GPU branch (barrier, final '
                          'gather inside the timed region, MAX all-reduce of the time) -- a single-GPU rehearsal of what every rank of an N-GPU run does')
     ap.add_argument('--no-loop', action='store_true', help="skip the 'loop' object (the same step with the extra features computed on the device, "
                                                            'the eigensolver alone, one training step), measured after the headline')
-    ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (no gain at B=64: the GPU is saturated; no per-kernel events)')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto', nargs='?', const='on',
+                    help="replay every reverse step as a HIP graph (diffalign_amd/graphs.py: GraphedChain, what sample_one_batch does for small "
+                         "batches).  'auto' (default): as the sampling loop decides, i.e. for batches of at most graphs.CHAIN_GRAPH_MAX_PAIRS pairs -- "
+                         "not at the headline size, where the edge kernels hide the host; the training workload: 'on' captures the whole step")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -329,13 +335,25 @@ def main():
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
 
-    if args.graph:
-        from diffalign_amd.graphs import GraphedReverseStep
-        gstep = GraphedReverseStep(model, data, z_t, pos, masks)
+    from diffalign_amd import graphs as G
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and G.chain_graphs_wanted(B, n))
+    eager_step = step
+    if use_graph:
+        # as sample_one_batch does for a batch of this size: every step a HIP graph of the same fused, three-stream work; the steps the
+        # timed region will replay are captured (once, untimed) before it starts
+        gc = G.GraphedChain.get(model, data, masks, pos, (1.0, 1.0), None, None, args.extra_features == 'device', 1)
+        cache = getattr(z_t, 'eig_cache', None)
+        gc.T_eval = T_eval
+        pad = torch.randn(B, n, device=dev)
+        gc.load(data, masks, pos, None, None, seeds, z_t, cache, pad)
 
-        def step():                                   # same work as above, replayed as one HIP graph
+        def step():
             t = state['t']
-            gstep.step(t)
+            g = gc.graphs.get(t)
+            if g is None:
+                gc.run_steps(t, t)
+            else:
+                g.replay()
             state['t'] = t - 1 if t > 1 else 50
 
     def sync():
@@ -344,9 +362,22 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        if use_graph:
+            for _ in range(2):                                # the edge kernel's live timing: two eager steps (a graph has no events inside)
+                eager_step()
+            engine.PROFILE_EVENTS = []
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            ev_eager = engine.PROFILE_EVENTS
+            engine.PROFILE_EVENTS = None
+            state['t'] = 50
+            for _ in range(args.warmup + args.steps):         # capture the steps the timed region replays
+                step()
+            state['t'] = 50
         for _ in range(args.warmup):
             step()
-        engine.PROFILE_EVENTS = []
+        engine.PROFILE_EVENTS = [] if not use_graph else None
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -358,7 +389,7 @@ def main():
             gather_collapsed(z_t.X.argmax(-1).to(torch.uint8), z_t.E.argmax(-1).to(torch.uint8))
         sync()
         dt = time.perf_counter() - t0
-    ev = engine.PROFILE_EVENTS
+    ev = engine.PROFILE_EVENTS if not use_graph else ev_eager
     engine.PROFILE_EVENTS = None
     edge_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
     if dist is not None:
@@ -411,9 +442,10 @@ def main():
                                        f'NOT the headline -- USPTO-like product sizes (P ~ N(26,10), {float(true["node_mask"].float().mean()):.0%} real '
                                        f'nodes) padded to n={n}, batch {B}/GPU, same network and step'),
                           'extra_features': 'given as inputs (SURVEY 8d)' if args.extra_features == 'inputs' else 'computed on the device inside the step',
-                          'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)'},
+                          'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)',
+                          'hip_graph_per_step': bool(use_graph)},
                'roofline': roof}
-        if world == 1 and not args.no_loop and args.extra_features == 'inputs' and not args.graph:
+        if world == 1 and not args.no_loop and args.extra_features == 'inputs' and not use_graph:
             out['loop'] = loop_object(args, model, step, z_t, data, masks, dev)
             del model, z_t
             torch.cuda.empty_cache()

@@ -41,7 +41,11 @@ SIGNATURES = {
     'da_skip_grad': 'i:pppipippiiiip',
     'da_attn_core_fwd': 'i:ppppppppfppppiiip',
     'da_attn_core_bwd': 'i:pppppppfpppppppppppppqiiip', 'da_attn_core_bwd_workspace': 'q:iii',
+    'da_attn_core_fwd_bf16': 'i:ppppppppfppppiiip', 'da_attn_core_bwd_bf16': 'i:pppppppfpppppppppppppqiiip',
+    'da_linear_wgrad_mixed': 'i:pipipppqqiip',
     'da_layernorm_bwd': 'i:pppppppqqip',
+    'da_res_ln_fwd': 'i:ppipiipppifpppqip', 'da_res_ln_bwd_workspace': 'q:i', 'da_res_ln_bwd': 'i:pppppiipifppipppqqip',
+    'da_relu_dropout': 'i:piqpifp', 'da_relu_dropout_bwd': 'i:pppiqfp',
     'da_pool_stats_fwd': 'i:ppppqiiip', 'da_linear_wgrad_workspace': 'q:qii', 'da_linear_wgrad': 'i:pppppqqiip',
     'da_pool_stats_bwd': 'i:pppppiiip',
     'da_vb_grad': 'i:ppppppppppppppffppiiiip',

@@ -26,10 +26,13 @@ _WS = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only scratch per device for the two-stage kernels (partial results); calls on one stream are ordered, so it is shared."""
-    w = _WS.get(device)
+    """Grow-only scratch per (device, stream) for the two-stage kernels (partial results): calls on one stream are ordered, so they
+    share it; the node and pair sides of the training step run on two streams (train_forward.py) and must not.  A buffer that is
+    outgrown is handed back through the allocator, which defers its reuse behind the stream's pending work."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _WS.get(key)
     if w is None or w.numel() < nbytes:
-        w = _WS[device] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        w = _WS[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     return w
 
 
@@ -42,15 +45,24 @@ class WideLinear(Function):
     the library runs on a few workgroups -- go to da_linear_wgrad (split over rows, fp32 MFMA)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        return torch.nn.functional.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, act=None):
+        out = torch.nn.functional.linear(x, weight, bias)
+        ctx.act = act is not None
+        if act is not None:                     # dropout_p(relu(.)) in place on the result (act = (seed, salt, p): da_relu_dropout)
+            _relu_dropout_(out, *act)
+            ctx.p = float(act[2])
+            ctx.save_for_backward(x, weight, out)
+        else:
+            ctx.save_for_backward(x, weight)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         out_f, in_f = weight.shape
         dy = _c(dy)
+        if ctx.act:
+            dy = _relu_dropout_bwd(ctx.saved_tensors[2], dy, ctx.p)
         dx = dy @ weight if ctx.needs_input_grad[0] else None
         R = x.numel() // in_f
         x2, dy2 = _c(x).reshape(R, in_f), dy.reshape(R, out_f)
@@ -59,15 +71,75 @@ class WideLinear(Function):
         ws = _workspace(x.device, nbytes)
         L.check(L.lib().da_linear_wgrad(L.ptr(x2), L.ptr(dy2), L.ptr(dW), L.ptr(db), L.ptr(ws), ws.numel(), R, in_f, out_f, L.stream()),
                 'da_linear_wgrad')
-        return dx, dW, db
+        return dx, dW, db, None
 
 
-def wide_linear(lin: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    """`lin(x)` for per-pair inputs: WideLinear where da_linear_wgrad is built for the shape and the row count makes it pay."""
+class WideLinearBF16(Function):
+    """WideLinear in mixed precision (the reference trains under fp16 autocast, diffusion_abstract.py:181-183): x, the weight copy and the
+    result are bf16 (library GEMM, fp32 accumulation), dX is a bf16 GEMM, dW / db come from da_linear_wgrad_mixed -- bf16 operands
+    widened on load, fp32 products and reduction -- as fp32 gradients of the fp32 master weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act=None):
+        wb = weight.to(torch.bfloat16)
+        out = torch.nn.functional.linear(x, wb, bias.to(torch.bfloat16))
+        ctx.act = act is not None
+        if act is not None:
+            _relu_dropout_(out, *act)
+            ctx.p = float(act[2])
+            ctx.save_for_backward(x, wb, out)
+        else:
+            ctx.save_for_backward(x, wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors[:2]
+        out_f, in_f = wb.shape
+        dy = dy.contiguous()
+        if ctx.act:
+            dy = _relu_dropout_bwd(ctx.saved_tensors[2], dy, ctx.p)
+        dx = dy @ wb if ctx.needs_input_grad[0] else None
+        R = x.numel() // in_f
+        x2, dy2 = x.contiguous().reshape(R, in_f), dy.reshape(R, out_f)
+        dW = torch.empty(out_f, in_f, device=x.device); db = torch.empty(out_f, device=x.device)
+        ws = _workspace(x.device, L.lib().da_linear_wgrad_workspace(R, in_f, out_f))
+        L.check(L.lib().da_linear_wgrad_mixed(L.ptr(x2), int(x2.dtype == torch.bfloat16), L.ptr(dy2), int(dy2.dtype == torch.bfloat16), L.ptr(dW),
+                                              L.ptr(db), L.ptr(ws), ws.numel(), R, in_f, out_f, L.stream()), 'da_linear_wgrad_mixed')
+        return dx, dW, db, None
+
+
+def _relu_dropout_(h, seed, salt, p):
+    p = float(p)
+    L.check(L.lib().da_relu_dropout(L.ptr(h), int(h.dtype == torch.bfloat16), h.numel(), L.ptr(seed if p > 0 else None), salt, p, L.stream()),
+            'da_relu_dropout')
+    return h
+
+
+def _relu_dropout_bwd(h, dy, p):
+    dy = dy.contiguous()
+    if dy.dtype != h.dtype:
+        dy = dy.to(h.dtype)
+    dx = torch.empty_like(h)
+    L.check(L.lib().da_relu_dropout_bwd(L.ptr(h), L.ptr(dy), L.ptr(dx), int(h.dtype == torch.bfloat16), h.numel(), float(p), L.stream()),
+            'da_relu_dropout_bwd')
+    return dx
+
+
+def wide_linear(lin: torch.nn.Linear, x: torch.Tensor, act=None) -> torch.Tensor:
+    """`lin(x)` for per-pair inputs: WideLinear where da_linear_wgrad is built for the shape and the row count makes it pay.  A bf16
+    input selects the mixed-precision form (bf16 in, bf16 out).  `act` = (seed, salt, p): dropout_p(relu(lin(x))), applied in place on
+    the GEMM's result (csrc/k_train_fused.hip)."""
     shape = (lin.in_features, lin.out_features)
-    if shape in _WGRAD_SHAPES and x.numel() // lin.in_features >= WIDE_MIN_ROWS and lin.bias is not None and torch.is_grad_enabled():
-        return WideLinear.apply(x, lin.weight, lin.bias)
-    return lin(x)
+    if x.dtype == torch.bfloat16:
+        if shape in _WGRAD_SHAPES and lin.bias is not None and torch.is_grad_enabled():
+            return WideLinearBF16.apply(x, lin.weight, lin.bias, act)
+        out = torch.nn.functional.linear(x, lin.weight.to(torch.bfloat16), None if lin.bias is None else lin.bias.to(torch.bfloat16))
+    elif shape in _WGRAD_SHAPES and x.numel() // lin.in_features >= WIDE_MIN_ROWS and lin.bias is not None and torch.is_grad_enabled():
+        return WideLinear.apply(x, lin.weight, lin.bias, act)
+    else:
+        out = lin(x)
+    return out if act is None else ReluDropout.apply(out, *act)
 
 
 class AttnCore(Function):
@@ -100,6 +172,38 @@ class AttnCore(Function):
         return dQ, dK, dV, dE1, dE2, None, dye1, dye2, None
 
 
+class AttnCoreBF16(Function):
+    """AttnCore with the per-pair tensors in bf16 storage: E1, E2 in, Z out, and dZ in, dE1, dE2 out in the backward; q, k, v, the FiLM
+    vectors, the softmax statistics and all arithmetic stay fp32 (da_attn_core_fwd_bf16 / _bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, E1, E2, nm_u8, ye1, ye2, qscale):
+        Q, K, V, ye1, ye2 = map(_c, (Q, K, V, ye1, ye2))
+        E1, E2 = E1.contiguous(), E2.contiguous()
+        assert E1.dtype == torch.bfloat16 and E2.dtype == torch.bfloat16
+        B, n, dx = Q.shape
+        Z = torch.empty_like(E1); wV = torch.empty_like(Q); sm = torch.empty_like(Q); sl = torch.empty_like(Q)
+        L.check(L.lib().da_attn_core_fwd_bf16(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm_u8), L.ptr(ye1), L.ptr(ye2), float(qscale),
+                                              L.ptr(Z), L.ptr(wV), L.ptr(sm), L.ptr(sl), B, n, dx, L.stream()), 'da_attn_core_fwd_bf16')
+        ctx.save_for_backward(Q, K, V, E1, E2, nm_u8, ye2, wV, sm, sl)
+        ctx.qscale = float(qscale)
+        return Z, wV
+
+    @staticmethod
+    def backward(ctx, dZ, dwV):
+        Q, K, V, E1, E2, nm_u8, ye2, wV, sm, sl = ctx.saved_tensors
+        B, n, dx = Q.shape
+        dZ, dwV = dZ.contiguous().to(torch.bfloat16), _c(dwV)
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+        dE1, dE2 = torch.empty_like(E1), torch.empty_like(E1)
+        dye1, dye2 = torch.empty_like(ye2), torch.empty_like(ye2)
+        ws = _workspace(Q.device, L.lib().da_attn_core_bwd_workspace(B, n, dx))
+        L.check(L.lib().da_attn_core_bwd_bf16(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm_u8), L.ptr(ye2), ctx.qscale, L.ptr(wV),
+                                              L.ptr(sm), L.ptr(sl), L.ptr(dZ), L.ptr(dwV), L.ptr(dQ), L.ptr(dK), L.ptr(dV), L.ptr(dE1), L.ptr(dE2),
+                                              L.ptr(dye1), L.ptr(dye2), L.ptr(ws), ws.numel(), B, n, dx, L.stream()), 'da_attn_core_bwd_bf16')
+        return dQ, dK, dV, dE1, dE2, None, dye1, dye2, None
+
+
 class AddLayerNorm(Function):
     """LayerNorm(a + b) (post-LN residual blocks, layers.py:341-359), eps 1e-5."""
 
@@ -124,6 +228,70 @@ class AddLayerNorm(Function):
         L.check(L.lib().da_layernorm_bwd(L.ptr(s), L.ptr(g), L.ptr(dy), L.ptr(ds), L.ptr(dg), L.ptr(db), L.ptr(ws), ws.numel(), s.numel() // D, D,
                                          L.stream()), 'da_layernorm_bwd')
         return ds, ds, dg, db
+
+
+FUSED_WIDTHS = (16, 32, 64, 128, 256)
+
+
+class ResidualLN(Function):
+    """One residual block of XEyTransformerLayer (layers.py:341-359) as one kernel each way: out = LayerNorm(res + dropout_p(mask(u))),
+    returned as (out fp32, out bf16 or None).  `u` fp32 or bf16; mask_mode 0 none / 1 node rows / 2 pairs (da_res_ln_fwd); dropout
+    bits are a hash of (element, *seed, salt), regenerated in the backward, so no mask is stored (csrc/k_train_fused.hip)."""
+
+    @staticmethod
+    def forward(ctx, res, u, nm_u8, mask_mode, n, gamma, beta, seed, salt, p, want_bf16):
+        res = _c16(res)
+        ub = u.dtype == torch.bfloat16
+        u = u.contiguous() if ub else _c16(u)
+        D = res.shape[-1]
+        s = torch.empty_like(res); out = torch.empty_like(res)
+        ob = torch.empty(res.shape, dtype=torch.bfloat16, device=res.device) if want_bf16 else None
+        g, be = _c(gamma), _c(beta)
+        p = float(p)
+        L.check(L.lib().da_res_ln_fwd(L.ptr(res), L.ptr(u), int(ub), L.ptr(nm_u8 if mask_mode else None), mask_mode, n, L.ptr(g), L.ptr(be),
+                                      L.ptr(seed if p > 0 else None), salt, p, L.ptr(s), L.ptr(out), L.ptr(ob), res.numel() // D, D,
+                                      L.stream()), 'da_res_ln_fwd')
+        ctx.save_for_backward(s, g, nm_u8, seed)
+        ctx.meta = (mask_mode, n, salt, p, ub, u.dtype)
+        ctx.set_materialize_grads(False)
+        return out, ob
+
+    @staticmethod
+    def backward(ctx, d_out, d_ob):
+        s, g, nm_u8, seed = ctx.saved_tensors
+        mask_mode, n, salt, p, ub, udt = ctx.meta
+        D = s.shape[-1]
+        if d_out is None and d_ob is None:
+            return (None,) * 11
+        d_out = None if d_out is None else _c16(d_out)
+        d_ob = None if d_ob is None else d_ob.contiguous()
+        ds = torch.empty_like(s)
+        du = torch.empty(s.shape, dtype=udt, device=s.device) if ctx.needs_input_grad[1] else None
+        dg = torch.empty(D, device=s.device); db = torch.empty(D, device=s.device)
+        ws = _workspace(s.device, L.lib().da_res_ln_bwd_workspace(D))
+        L.check(L.lib().da_res_ln_bwd(L.ptr(s), L.ptr(g), L.ptr(d_out), L.ptr(d_ob), L.ptr(nm_u8 if mask_mode else None), mask_mode, n,
+                                      L.ptr(seed if p > 0 else None), salt, p, L.ptr(ds), L.ptr(du), int(ub), L.ptr(dg), L.ptr(db), L.ptr(ws),
+                                      ws.numel(), s.numel() // D, D, L.stream()), 'da_res_ln_bwd')
+        return ds, du, None, None, None, dg, db, None, None, None, None
+
+
+class ReluDropout(Function):
+    """dropout_p(relu(h)) IN PLACE on the output of the first Linear of a feed-forward branch (layers.py:349-357), fp32 or bf16; the
+    backward needs only the result (non-zero <=> passed the ReLU and kept by the dropout)."""
+
+    @staticmethod
+    def forward(ctx, h, seed, salt, p):
+        assert h.is_contiguous() and h.numel() % 4 == 0
+        _relu_dropout_(h, seed, salt, p)
+        ctx.mark_dirty(h)
+        ctx.save_for_backward(h)
+        ctx.p = float(p)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return _relu_dropout_bwd(h, dy, ctx.p), None, None, None
 
 
 class PoolStats(Function):

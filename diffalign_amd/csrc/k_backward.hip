@@ -133,10 +133,18 @@ __global__ void __launch_bounds__(256 * ATT_JS) k_attn_bwd(const float* __restri
 // (backward) meet in LDS.  Same arithmetic per element; sums over keys are grouped by slice.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// the per-pair streams (E1, E2, Z and their gradients) in bf16 storage (mixed-precision training: the reference trains under fp16
+// autocast, diffusion_abstract.py:181-183): four channels = 8 bytes; arithmetic stays fp32
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+}
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) { *reinterpret_cast<uint2*>(p) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}; }
+template <class TE>
 __global__ void __launch_bounds__(256) k_attn_fwd4(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                   const TE* __restrict__ E1, const TE* __restrict__ E2, const uint8_t* __restrict__ nm,
                                                    const float* __restrict__ ye1, const float* __restrict__ ye2, float qscale,
-                                                   float* __restrict__ Z, float* __restrict__ wV, float* __restrict__ smax,
+                                                   TE* __restrict__ Z, float* __restrict__ wV, float* __restrict__ smax,
                                                    float* __restrict__ ssum, int n, int dx) {
   extern __shared__ float s_st[];                                         // [3][JS][dx]: running max, sum, weighted sum per slice
   const int CW4 = dx >> 2, JS = 256 / CW4;
@@ -188,14 +196,14 @@ __global__ void __launch_bounds__(256) k_attn_fold(const float* __restrict__ pK,
   for (int g = 0; g < nblk; ++g) { a += ld4(pK + ((size_t)g * quads + t) * 4); b += ld4(pV + ((size_t)g * quads + t) * 4); }
   st4(dK + t * 4, a); st4(dV + t * 4, b);
 }
-template <int IB>
+template <int IB, class TE>
 __global__ void __launch_bounds__(256) k_attn_bwd4(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                   const float* __restrict__ E1, const float* __restrict__ E2, const uint8_t* __restrict__ nm,
+                                                   const TE* __restrict__ E1, const TE* __restrict__ E2, const uint8_t* __restrict__ nm,
                                                    const float* __restrict__ ye2, float qscale, const float* __restrict__ wV,
                                                    const float* __restrict__ smax, const float* __restrict__ ssum,
-                                                   const float* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
-                                                   float* __restrict__ dKp, float* __restrict__ dVp, float* __restrict__ dE1,
-                                                   float* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
+                                                   const TE* __restrict__ dZ, const float* __restrict__ dwV, float* __restrict__ dQ,
+                                                   float* __restrict__ dKp, float* __restrict__ dVp, TE* __restrict__ dE1,
+                                                   TE* __restrict__ dE2, float* __restrict__ dye1, float* __restrict__ dye2, int n, int dx) {
   // dKp, dVp (gridDim.x, B, n, dx): this row block's contribution to dK, dV, every element written once (k_attn_fold sums the blocks
   // in order).  With fp32 atomics on dK / dV instead, the kernel's time was proportional to the number of atomics (2.25 / 1.19 / 0.74 ms
   // for 1 / 2 / 4 rows per block against ~0.2 ms of streaming).
@@ -475,8 +483,17 @@ __global__ void __launch_bounds__(256) k_vb_grad(const float* __restrict__ tr, c
 // with m = output feature, n = input feature and k = two consecutive rows, both operands are plain coalesced row reads from HBM
 // (no LDS, no transposes).  Stage 2 sums the slices' partial results in slice order (deterministic).
 #define WG_U 8                                                            // row pairs per software-pipeline stage
-template <int IN, int OUT, int WI, int WJ>
-__global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ part,
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+// bf16 operands stay RAW (the zero-extended 16 bits) in the pipeline registers and are widened where the MFMA consumes them: a
+// conversion at the load would pin an s_waitcnt to the load stage and serialise the software pipeline.
+__device__ __forceinline__ unsigned ld_raw(const bf16_t* p) { return *reinterpret_cast<const unsigned short*>(p); }
+__device__ __forceinline__ float ld_raw(const float* p) { return *p; }
+__device__ __forceinline__ float widen(unsigned r) { return __builtin_bit_cast(float, r << 16); }
+__device__ __forceinline__ float widen(float r) { return r; }
+template <class T> struct RawOf { using type = float; };
+template <> struct RawOf<bf16_t> { using type = unsigned; };
+template <int IN, int OUT, int WI, int WJ, class TX = float, class TY = float>
+__global__ void __launch_bounds__(256) k_wgrad_partial(const TX* __restrict__ X, const TY* __restrict__ dY, float* __restrict__ part,
                                                        float* __restrict__ bpart, long long R, int rows_per_wg) {
   static_assert(WI * WJ == 4 && (IN / 32) % WI == 0 && (OUT / 32) % WJ == 0, "tiling");
   constexpr int TI = IN / 32 / WI, TJ = OUT / 32 / WJ;
@@ -493,36 +510,45 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float* __restrict__
   float bs[TJ];
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) bs[tj] = 0.f;
-  const float* xp = X + (wi * TI) * 32 + l32;
-  const float* yp = dY + (wj * TJ) * 32 + l32;
-  float a[2][WG_U][TJ], bb[2][WG_U][TI];
+  const TX* xp = X + (wi * TI) * 32 + l32;
+  const TY* yp = dY + (wj * TJ) * 32 + l32;
+  typename RawOf<TY>::type a[2][WG_U][TJ];
+  typename RawOf<TX>::type bb[2][WG_U][TI];
+  // rows past the slice are CLAMPED to its last row at the load (no exec-masked branch around a load: that would put a wait inside the
+  // load stage) and their dY operand is zeroed where it is consumed, which removes them from dW and db alike
   auto load = [&](int buf, long long r) {
 #pragma unroll
     for (int u = 0; u < WG_U; ++u) {
-      const long long rr = r + 2 * u + lh;
-      const bool ok = rr < r1;
+      const long long rr = min(r + 2 * u + lh, r1 - 1);
 #pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) a[buf][u][tj] = ok ? yp[rr * OUT + tj * 32] : 0.f;
+      for (int tj = 0; tj < TJ; ++tj) a[buf][u][tj] = ld_raw(yp + rr * OUT + tj * 32);
 #pragma unroll
-      for (int ti = 0; ti < TI; ++ti) bb[buf][u][ti] = ok ? xp[rr * IN + ti * 32] : 0.f;
+      for (int ti = 0; ti < TI; ++ti) bb[buf][u][ti] = ld_raw(xp + rr * IN + ti * 32);
     }
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, long long r) {
 #pragma unroll
-    for (int u = 0; u < WG_U; ++u)
+    for (int u = 0; u < WG_U; ++u) {
+      const bool ok = r + 2 * u + lh < r1;
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) {
-        bs[tj] += a[buf][u][tj];
+        const float av = ok ? widen(a[buf][u][tj]) : 0.f;
+        bs[tj] += av;
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][tj], bb[buf][u][ti], acc[tj][ti], 0, 0, 0);
+        for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, widen(bb[buf][u][ti]), acc[tj][ti], 0, 0, 0);
       }
+    }
   };
   load(0, r0);
   for (long long r = r0; r < r1; r += 4 * WG_U) {                         // two stages per trip: the loads of one run under the MFMAs of the other
     load(1, r + 2 * WG_U);
-    compute(0);
+    __builtin_amdgcn_sched_barrier(0);                                    // keep the stages apart: the scheduler otherwise sinks every load
+    compute(0, r);                                                        // to just before its MFMA and waits for it there
+    __builtin_amdgcn_sched_barrier(0);
     load(0, r + 4 * WG_U);
-    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, r + 2 * WG_U);
+    __builtin_amdgcn_sched_barrier(0);
   }
   float* pw = part + (size_t)blockIdx.x * OUT * IN;
 #pragma unroll
@@ -570,17 +596,30 @@ __global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ pa
   }
 }
 #define WGRAD_MAX_SLICES 512
-template <int IN, int OUT, int WI, int WJ>
-static void launch_wgrad(const float* X, const float* dY, float* dW, float* db, float* ws, long long R, hipStream_t s) {
+template <int IN, int OUT, int WI, int WJ, class TX = float, class TY = float>
+static void launch_wgrad(const TX* X, const TY* dY, float* dW, float* db, float* ws, long long R, hipStream_t s) {
   long long per = (R + WGRAD_MAX_SLICES - 1) / WGRAD_MAX_SLICES;
   per = (per + 1) & ~1LL;                                                 // rows are consumed in pairs
   if (per < 64) per = 64;
   const int G = (int)((R + per - 1) / per);
   float* bpart = ws + (size_t)G * OUT * IN;
-  k_wgrad_partial<IN, OUT, WI, WJ><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
+  k_wgrad_partial<IN, OUT, WI, WJ, TX, TY><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
   k_wgrad_fold<<<(IN * OUT + OUT + 31) / 32, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
 }
 
+template <class TX, class TY>
+static int wgrad_typed(const TX* X, const TY* dY, float* dW, float* db, float* ws, long long R, int in_features, int out_features, hipStream_t s) {
+  switch (in_features * 1000 + out_features) {
+    case 64256: launch_wgrad<64, 256, 1, 4, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    case 256064: launch_wgrad<256, 64, 4, 1, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    case 64128: launch_wgrad<64, 128, 1, 4, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    case 128064: launch_wgrad<128, 64, 4, 1, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    case 64064: launch_wgrad<64, 64, 2, 2, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    case 128128: launch_wgrad<128, 128, 2, 2, TX, TY>(X, dY, dW, db, ws, R, s); break;
+    default: da_set_error("da_linear_wgrad_mixed: %d -> %d features not built", in_features, out_features); return DA_ERR_UNSUPPORTED;
+  }
+  return DA_OK;
+}
 // ---------------------------------------------------------------------------------------------------------------------------------
 // AdamW(amsgrad) on a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay, bias corrections by step).
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -649,7 +688,7 @@ int da_attn_core_fwd(const float* Q, const float* K, const float* V, const float
                        (uintptr_t)wV | (uintptr_t)smax | (uintptr_t)ssum) & 15) == 0);
   if (quad) {
     const int JS = 256 / (dx / 4);
-    k_attn_fwd4<<<dim3(n, B), 256, sizeof(float) * 3 * JS * dx, (hipStream_t)stream>>>(Q, K, V, E1, E2, node_mask, ye1, ye2, qscale, Z, wV, smax, ssum, n, dx);
+    k_attn_fwd4<float><<<dim3(n, B), 256, sizeof(float) * 3 * JS * dx, (hipStream_t)stream>>>(Q, K, V, E1, E2, node_mask, ye1, ye2, qscale, Z, wV, smax, ssum, n, dx);
     DA_CHECK_LAUNCH("da_attn_core_fwd");
     return DA_OK;
   }
@@ -686,7 +725,7 @@ int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float
   if (quad) {                                                               // dK, dV: per-block partials + ordered fold, no atomics
     const int JS = 256 / (dx / 4), nblk = (n + QIB - 1) / QIB;
     float* pK = (float*)workspace; float* pV = pK + (size_t)nblk * B * n * dx;
-    k_attn_bwd4<QIB><<<dim3(nblk, B), 256, sizeof(float) * JS * (QIB + 2) * dx, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ,
+    k_attn_bwd4<QIB, float><<<dim3(nblk, B), 256, sizeof(float) * JS * (QIB + 2) * dx, s>>>(Q, K, V, E1, E2, node_mask, ye2, qscale, wV, smax, ssum, dZ, dwV, dQ,
                                                                                  pK, pV, dE1, dE2, dye1, dye2, n, dx);
     const long long quads = (long long)B * n * dx / 4;
     k_attn_fold<<<grid_for(quads, 256), 256, 0, s>>>(pK, pV, dK, dV, nblk, quads);
@@ -706,6 +745,44 @@ int da_attn_core_bwd(const float* Q, const float* K, const float* V, const float
   }
 #undef ATT_LAUNCH
   DA_CHECK_LAUNCH("da_attn_core_bwd");
+  return DA_OK;
+}
+
+// The attention core with the per-pair streams in bf16 storage (E1, E2, Z / dZ, dE1, dE2); everything per node and per graph stays
+// fp32, as does the arithmetic.  dx % 4 == 0 with dx / 4 dividing 256 (the quad kernels); pair streams 8-byte aligned.
+static bool quad_ok(int dx) { return dx % 4 == 0 && dx / 4 <= 256 && 256 % (dx / 4) == 0; }
+int da_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, const void* E1, const void* E2, const uint8_t* node_mask,
+                          const float* ye1, const float* ye2, float qscale, void* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
+                          void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0 && quad_ok(dx), "da_attn_core_fwd_bf16: dx = %d must be a multiple of 4 with dx / 4 dividing 256", dx);
+  DA_CHECK_ARG(((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)ye1 | (uintptr_t)ye2 | (uintptr_t)wV | (uintptr_t)smax | (uintptr_t)ssum) & 15) == 0) &&
+               ((((uintptr_t)E1 | (uintptr_t)E2 | (uintptr_t)Z) & 7) == 0), "da_attn_core_fwd_bf16: unaligned tensor");
+  if (B == 0 || n == 0) return DA_OK;
+  const int JS = 256 / (dx / 4);
+  k_attn_fwd4<bf16_t><<<dim3(n, B), 256, sizeof(float) * 3 * JS * dx, (hipStream_t)stream>>>(Q, K, V, (const bf16_t*)E1, (const bf16_t*)E2, node_mask, ye1,
+                                                                                      ye2, qscale, (bf16_t*)Z, wV, smax, ssum, n, dx);
+  DA_CHECK_LAUNCH("da_attn_core_fwd_bf16");
+  return DA_OK;
+}
+int da_attn_core_bwd_bf16(const float* Q, const float* K, const float* V, const void* E1, const void* E2, const uint8_t* node_mask,
+                          const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const void* dZ, const float* dwV,
+                          float* dQ, float* dK, float* dV, void* dE1, void* dE2, float* dye1, float* dye2, void* workspace, long long workspace_bytes,
+                          int B, int n, int dx, void* stream) {
+  DA_CHECK_ARG(B >= 0 && n >= 0 && quad_ok(dx), "da_attn_core_bwd_bf16: dx = %d must be a multiple of 4 with dx / 4 dividing 256", dx);
+  if (B == 0 || n == 0) return DA_OK;
+  constexpr int QIB = 4;
+  DA_CHECK_ARG(workspace && workspace_bytes >= da_attn_core_bwd_workspace(B, n, dx), "da_attn_core_bwd_bf16: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t yb = sizeof(float) * (size_t)B * dx;
+  if (hipMemsetAsync(dye1, 0, yb, s) != hipSuccess || hipMemsetAsync(dye2, 0, yb, s) != hipSuccess) { da_set_error("da_attn_core_bwd_bf16: memset failed"); return DA_ERR_HIP; }
+  const int JS = 256 / (dx / 4), nblk = (n + QIB - 1) / QIB;
+  float* pK = (float*)workspace; float* pV = pK + (size_t)nblk * B * n * dx;
+  k_attn_bwd4<QIB, bf16_t><<<dim3(nblk, B), 256, sizeof(float) * JS * (QIB + 2) * dx, s>>>(Q, K, V, (const bf16_t*)E1, (const bf16_t*)E2, node_mask, ye2, qscale,
+                                                                                      wV, smax, ssum, (const bf16_t*)dZ, dwV, dQ, pK, pV, (bf16_t*)dE1,
+                                                                                      (bf16_t*)dE2, dye1, dye2, n, dx);
+  const long long quads = (long long)B * n * dx / 4;
+  k_attn_fold<<<grid_for(quads, 256), 256, 0, s>>>(pK, pV, dK, dV, nblk, quads);
+  DA_CHECK_LAUNCH("da_attn_core_bwd_bf16");
   return DA_OK;
 }
 
@@ -782,6 +859,25 @@ int da_linear_wgrad(const float* X, const float* dY, float* dW, float* db, void*
                           out_features); return DA_ERR_UNSUPPORTED;
   }
   DA_CHECK_LAUNCH("da_linear_wgrad");
+  return DA_OK;
+}
+
+// da_linear_wgrad with X and / or dY in bf16 storage (x_bf16 / dy_bf16 != 0); the products and the reduction stay fp32 (the elements
+// are widened on load and go through the same v_mfma_f32_32x32x2_f32 tiles): what changes is the bytes of the (R, 256) stream.
+int da_linear_wgrad_mixed(const void* X, int x_bf16, const void* dY, int dy_bf16, float* dW, float* db, void* workspace, long long workspace_bytes,
+                          long long R, int in_features, int out_features, void* stream) {
+  DA_CHECK_ARG(R >= 1 && X && dY && dW && workspace, "da_linear_wgrad_mixed: arguments");
+  DA_CHECK_ARG(workspace_bytes >= da_linear_wgrad_workspace(R, in_features, out_features), "da_linear_wgrad_mixed: workspace of %lld bytes is too small",
+               workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  int rc;
+  if (x_bf16 && dy_bf16) rc = wgrad_typed((const bf16_t*)X, (const bf16_t*)dY, dW, db, ws, R, in_features, out_features, s);
+  else if (x_bf16) rc = wgrad_typed((const bf16_t*)X, (const float*)dY, dW, db, ws, R, in_features, out_features, s);
+  else if (dy_bf16) rc = wgrad_typed((const float*)X, (const bf16_t*)dY, dW, db, ws, R, in_features, out_features, s);
+  else rc = wgrad_typed((const float*)X, (const float*)dY, dW, db, ws, R, in_features, out_features, s);
+  if (rc) return rc;
+  DA_CHECK_LAUNCH("da_linear_wgrad_mixed");
   return DA_OK;
 }
 

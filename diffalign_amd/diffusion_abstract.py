@@ -127,6 +127,8 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                 self._extra_calc = (XF.ExtraFeatures('all', self.dataset_info), XF.ExtraMolecularFeatures(self.dataset_info))
             # `eig_cache`: set on the chain's state object by sample_one_batch (the fixed product block's part of the eigensolver
             # is kept along the chain); objects derived from it (get_new_object) do not carry it
+            if pad_noise is None:
+                pad_noise = getattr(noisy_data, 'pad_noise', None)                # per chain (sample_one_batch)
             X_extra, y_extra = XF.compute_extra_features(noisy_data.X, noisy_data.E, noisy_data.node_mask, *self._extra_calc,
                                                          pad_noise=pad_noise, eig_cache=getattr(noisy_data, 'eig_cache', None))
         # a view of noisy_data with widened X and y: the reference's get_new_object clones every field (E: 161 MB at the
@@ -136,7 +138,7 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                            mol_assignments=noisy_data.mol_assignments)
 
     def reverse_step(self, z_t, t_array, pos_encodings=None, transition_model=None, temperature=(1.0, 1.0), noise=None, chain_seeds=None,
-                     call=0, orig=None, node_masks=None, generator=None, want_logits=False, t_int=None):
+                     call=0, orig=None, node_masks=None, generator=None, want_logits=False, t_int=None, tables=None):
         """One reverse step p(z_s | z_t) (diffusion/sampling.py:76-86,165-178): denoiser forward + posterior + categorical draw +
         apply_mask.  With 7 edge classes the edge half is drawn inside the denoiser's output kernel (da_edge_out_sample; the
         (B,n,n,7) logits and noise tensors never reach HBM); otherwise forward() + helpers.posterior_sample.  Both give the same
@@ -144,7 +146,9 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         `t_int`: the step number when all graphs share it (then t_array is not read for the tables)."""
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
-        if t_int is not None:        # every graph is at step t_int (the sampling loop): slices of tables laid out once per batch size
+        if tables is not None:       # (Q_t, Qbar_{t-1}, Qbar_t) of this step laid out by the caller (graphs.GraphedChain)
+            Qt, Qsb, Qtb = tables
+        elif t_int is not None:      # every graph is at step t_int (the sampling loop): slices of tables laid out once per batch size
             Qt, Qsb, Qtb = tm.step_tables(int(t_int), z_t.X.shape[0])
         else:
             Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)

@@ -49,7 +49,7 @@ class DiscreteDenoisingDiffusionRxn(DiscreteDenoisingDiffusion):
         rep = lambda idx: [item for item in idx for _ in range(n_samples)] if idx is not None else None
         final_samples = self.sample_one_batch(data=dup, inpaint_node_idx=rep(inpaint_node_idx), inpaint_edge_idx=rep(inpaint_edge_idx),
                                               get_true_rxns=True, get_chains=True, device=device, noise_fn=noise_fn,
-                                              chain_seeds=chain_seeds)[0]
+                                              chain_seeds=chain_seeds, record_chains=False)[0]
         return final_samples
 
     @torch.no_grad()

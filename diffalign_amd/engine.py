@@ -40,6 +40,7 @@ def use_stats_tail(n: int) -> bool:
 # the caller's stream with the y chain and the node-feature work on two side streams (_layers_node_on_main), fused node input stage,
 # first layer from the input stage's class table, edge output as mirrored tiles with the reverse step drawn inside.  Under HIP-graph
 # capture (no side streams) the same kernels run on one stream (layer_forward).  The two attributes below are test hooks, not switches.
+CAPTURE_SIDE_STREAMS = True   # under HIP-graph capture the side streams join the capture through their events (False: one stream)
 TABLE_IN = True        # first edge layer reads its input rows from the input stage's table (da_edge_in_classes / da_edge_layer_table)
 SPLIT_TAIL = True      # load-balance the edge kernel's last round (da_edge_split_scratch_bytes); False: whole rows only
 PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
@@ -191,7 +192,8 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(B * n, dx, device=dev)
     ticket = pm.ticket if stats_out is not None else None
-    if PROFILE_EVENTS is not None:
+    profile = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
+    if profile:
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev0.record()
     args = (L.ptr(E_bf16), L.ptr(E_out), L.ptr(Qm), _i(Qm.shape[1]), L.ptr(kvf), L.ptr(nm_u8), L.ptr(ye2p1),
             L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
@@ -204,7 +206,7 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
         L.check(lib.da_edge_layer_stats(*args, L.ptr(stats_out), _i(stats_out.shape[1]), L.ptr(ticket), S), 'da_edge_layer_stats')
     else:
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
-    if PROFILE_EVENTS is not None:
+    if profile:
         ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
     return E_out, newX_in, split
 
@@ -305,7 +307,7 @@ def _side_stream(dev):
     layer l+1; the main stream joins right before the edge kernel of layer l+1.  A second side stream carries what depends on the
     node features only: the Xtoy statistics beside q/k/v, the node input / output paths beside the edge input / output
     stages, and (helpers.posterior_sample) the node half of the reverse step.  Returns (y stream, node stream) or None."""
-    if torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing() and not CAPTURE_SIDE_STREAMS:
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:

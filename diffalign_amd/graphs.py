@@ -1,65 +1,28 @@
-"""One reverse-diffusion step captured in a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm).
-
-A step is ~110 kernel launches issued from Python through ctypes; replaying them as one graph removes the host launch
-gaps (about 3 ms of a 22 ms step at B=64, n=300).  Everything that changes between steps lives in static device
-buffers that are overwritten before each replay: the state z_t (updated inside the graph), the step index y and the
-six gathered transition tables."""
+"""HIP graphs (torch.cuda.CUDAGraph = hipGraph on ROCm) of the two loops whose steps are launch-bound at small sizes: the reverse
+chain of small graphs (GraphedChain: one graph per step number, replayed for every chain of the same shape) and the training step
+(GraphedTrainStep: the whole step, one graph per batch shape)."""
 from __future__ import annotations
+
+import os
+from collections import OrderedDict
 
 import torch
 
 from . import helpers
 from .placeholder import PlaceHolder
 
+# Reverse chains of SMALL graphs are host-bound: a step is ~130 kernel launches behind ~2 ms of Python / ctypes, while the GPU needs
+# 2.6 ms at B = 100, n = 72 and less below.  GraphedChain replays every step as a HIP graph.  'auto': for batches of at most
+# CHAIN_GRAPH_MAX_PAIRS pairs (B n^2) -- above, the edge kernels hide the host (B = 64, n = 300: 5.8 M pairs).  '0' / '1' force it.
+CHAIN_GRAPHS = os.environ.get('DA_CHAIN_GRAPHS', 'auto')
+CHAIN_GRAPH_MAX_PAIRS = 1_600_000
+CHAIN_GRAPH_CACHE = 3            # shapes kept per model (each holds its graphs' private memory pool)
 
-class GraphedReverseStep:
-    def __init__(self, model, dense_data: PlaceHolder, z_t: PlaceHolder, pos_encodings, node_masks, temps=(1.0, 1.0),
-                 warmup: int = 2):
-        self.model, self.data, self.masks, self.temps, self.pos = model, dense_data, node_masks, temps, pos_encodings
-        dev = z_t.X.device
-        B, n, kx = z_t.X.shape
-        ke = z_t.E.shape[-1]
-        self.B = B
-        self.z = z_t.get_new_object(y=torch.zeros(B, 1, device=dev))
-        self.tabs = [torch.zeros(B, kx, kx, device=dev) for _ in range(3)] + [torch.zeros(B, ke, ke, device=dev) for _ in range(3)]
-        self.qX = torch.empty(B, n, kx, device=dev); self.qE = torch.empty(B, n, n, ke, device=dev)
-        self.tm = model.transition_model_eval
-        self.step_size = model.T // model.cfg.diffusion.diffusion_steps_eval
-        self._set_t(1)
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        keepX, keepE = self.z.X.clone(), self.z.E.clone()
-        with torch.cuda.stream(s), torch.no_grad():
-            for _ in range(warmup):
-                self._body()
-        torch.cuda.current_stream().wait_stream(s)
-        self.z.X.copy_(keepX); self.z.E.copy_(keepE)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._body()
-        self.z.X.copy_(keepX); self.z.E.copy_(keepE)
 
-    def _set_t(self, t: int):
-        t_arr = torch.full((self.B, 1), t, dtype=torch.long, device=self.z.X.device)
-        self.z.y.fill_(float(t * self.step_size))
-        Qt, Qsb, Qtb = self.tm.get_Qt(t_arr), self.tm.get_Qt_bar(t_arr - 1), self.tm.get_Qt_bar(t_arr)
-        for dst, src in zip(self.tabs, (Qt.X, Qsb.X, Qtb.X, Qt.E, Qsb.E, Qtb.E)):
-            dst.copy_(src)
-
-    def _body(self):
-        pred = self.model.forward(self.z, pos_encodings=self.pos)
-        self.qX.exponential_(1.0); self.qE.exponential_(1.0)
-        ph = lambda X, E: PlaceHolder(X=X, E=E, y=self.z.y)
-        _, _, zsX, zsE = helpers.posterior_sample(pred.X, pred.E, self.z, ph(self.tabs[0], self.tabs[3]), ph(self.tabs[1], self.tabs[4]),
-                                                  ph(self.tabs[2], self.tabs[5]), temperature=self.temps, noise=(self.qX, self.qE),
-                                                  orig=self.data, node_masks=self.masks)
-        self.z.X.copy_(zsX); self.z.E.copy_(zsE)
-
-    def step(self, t: int) -> PlaceHolder:
-        """z_t <- sample of p(z_{t-1} | z_t); returns the (static) state holder."""
-        self._set_t(t)
-        self.graph.replay()
-        return self.z
+def chain_graphs_wanted(B: int, n: int) -> bool:
+    if CHAIN_GRAPHS == '0' or torch.cuda.is_current_stream_capturing():
+        return False
+    return CHAIN_GRAPHS == '1' or B * n * n <= CHAIN_GRAPH_MAX_PAIRS
 
 
 class GraphedTrainStep:
@@ -122,3 +85,133 @@ class GraphedTrainStep:
         if getattr(self.model, 'ema', None) is not None:     # outside the graph: the decay schedule is host state
             self.model.ema.update()
         return self.loss
+
+
+class GraphedChain:
+    """The reverse chain of SamplingMixin.sample_one_batch for one batch shape, every step a HIP graph of the SAME work the eager loop
+    enqueues: the fused reverse step with its three-stream arrangement (engine._layers_node_on_main: the side streams join the
+    capture through their events), the extra features with the eigensolver's fixed-block cache, the draw from per-chain counter
+    noise, apply_mask and inpainting.  One graph per step number t (the step's transition tables, its y input and its noise call index
+    are constants of that graph), captured the first time the step runs and replayed for every later chain of the same shape; what a
+    chain brings -- condition, masks, positional encodings, seeds, inpainting lists, start state -- is copied into static buffers.
+    Same kernels, same arguments: the samples equal the eager loop's bit for bit (tests/test_gpu_sampling.py)."""
+
+    @staticmethod
+    def get(model, data: PlaceHolder, masks, pos, temps, fix_nodes, fix_edges, with_eig_cache: bool, first_call: int):
+        B, n, kx = data.X.shape
+        key = (B, n, kx, data.E.shape[-1], int(model.cfg.diffusion.diffusion_steps_eval), tuple(temps),
+               None if pos is None else tuple(pos.shape), None if fix_nodes is None else int(fix_nodes.shape[0]),
+               None if fix_edges is None else int(fix_edges.shape[0]), bool(with_eig_cache), int(first_call),
+               data.atom_map_numbers is not None, bool(model.cfg.diffusion.diffuse_edges), bool(model.cfg.diffusion.diffuse_nodes))
+        cache = model.__dict__.setdefault('_chain_graphs', OrderedDict())
+        pm = model._net()._pack(data.X.device)
+        if key in cache and cache[key].pm is not pm:
+            del cache[key]                                   # the weights moved: the packed bf16 copies the graphs point at are stale
+        if key not in cache:
+            while len(cache) >= CHAIN_GRAPH_CACHE:
+                cache.popitem(last=False)
+            cache[key] = GraphedChain(model, data, masks, pos, temps, fix_nodes, fix_edges, with_eig_cache, first_call)
+        cache.move_to_end(key)
+        return cache[key]
+
+    def __init__(self, model, data, masks, pos, temps, fix_nodes, fix_edges, with_eig_cache, first_call):
+        from . import _lib as L
+        from .extra_features import EigCache
+        dev = data.X.device
+        B, n, kx = data.X.shape
+        self.model, self.temps, self.first_call, self.B, self.n = model, tuple(temps), int(first_call), B, n
+        self.pm = model._net()._pack(dev)                    # the packed weights the graphs point at (kept alive; identity = freshness)
+        self.T_eval = int(model.cfg.diffusion.diffusion_steps_eval)
+        cl = lambda t: None if t is None else t.clone()
+        self.data = data.get_new_object()                                        # static copies (every tensor field cloned)
+        self.masks = (masks[0].clone(), masks[1].clone())
+        self.pos = cl(pos)
+        self.fix_nodes, self.fix_edges = cl(fix_nodes), cl(fix_edges)
+        self.seeds = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.pad_noise = torch.zeros(B, n, device=dev)
+        self.z = self.data.get_new_object(y=torch.zeros(B, 1, device=dev))
+        step = model.T // self.T_eval
+        self.all_t = torch.arange(self.T_eval + 1, device=dev)[:, None, None].expand(-1, B, 1).contiguous()
+        self.all_y = self.all_t.float() * step
+        tm = model.transition_model_eval
+        rep = lambda Q: Q[:, None].expand(-1, B, -1, -1).contiguous()
+        self.tabs = (rep(tm.Qts_x), rep(tm.Qts_e), rep(tm.Qt_bars_x), rep(tm.Qt_bars_e))   # this object's own: never re-laid-out
+        self.eig = None
+        if with_eig_cache:                                   # sized for any fixed block of this shape; filled per chain by load()
+            self.eig = EigCache(torch.zeros(B, dtype=torch.int32, device=dev), n)
+        self.graphs = {}
+        self.pool = torch.cuda.graph_pool_handle()
+        self.warm = False
+
+    def load(self, data, masks, pos, fix_nodes, fix_edges, seeds, z_start, eig_cache, pad_noise):
+        """A new chain of this shape: its inputs go into the static buffers, the eigensolver's cache starts empty."""
+        for name in ('X', 'E', 'y', 'node_mask', 'atom_map_numbers', 'mol_assignments'):
+            dst, src = getattr(self.data, name), getattr(data, name)
+            if dst is not None:
+                dst.copy_(src)
+        self.masks[0].copy_(masks[0]); self.masks[1].copy_(masks[1])
+        if self.pos is not None:
+            self.pos.copy_(pos)
+        if self.fix_nodes is not None:
+            self.fix_nodes.copy_(fix_nodes)
+        if self.fix_edges is not None:
+            self.fix_edges.copy_(fix_edges)
+        self.seeds.copy_(seeds)
+        self.pad_noise.copy_(pad_noise)
+        self.z.X.copy_(z_start.X); self.z.E.copy_(z_start.E)
+        for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
+            if getattr(self.z, name) is not None:
+                getattr(self.z, name).copy_(getattr(data, name))
+        if self.eig is not None:
+            self.eig.fixed_from.copy_(eig_cache.fixed_from)
+            self.eig.state.zero_()
+
+    def _tables(self, t):
+        qx, qe, bx, be = self.tabs
+        P = lambda X, E: PlaceHolder(X=X, E=E, y=None)
+        return P(qx[t], qe[t]), P(bx[t - 1], be[t - 1]), P(bx[t], be[t])
+
+    def _body(self, t):
+        from . import graph
+        m, z = self.model, self.z
+        z.eig_cache, z.pad_noise = self.eig, self.pad_noise
+        z.y = self.all_y[t]
+        zsX, zsE, _ = m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
+                                     orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
+                                     call=self.first_call + (self.T_eval - t), tables=self._tables(t))
+        z.X.copy_(zsX); z.E.copy_(zsE)
+        graph.apply_inpainting(z, self.data, self.fix_nodes, self.fix_edges)
+        if not m.cfg.diffusion.diffuse_edges:
+            z.E.copy_(self.data.E)
+        if not m.cfg.diffusion.diffuse_nodes:
+            z.X.copy_(self.data.X)
+
+    def run(self):
+        """All T_eval steps on the loaded chain; returns the static state holder (clone what must outlive the next chain)."""
+        return self.run_steps(self.T_eval, 1)
+
+    def run_steps(self, t_from: int, t_to: int):
+        """Steps t_from, t_from - 1, ..., t_to on the loaded chain."""
+        with torch.no_grad():
+            for t in range(t_from, t_to - 1, -1):
+                g = self.graphs.get(t)
+                if g is None:
+                    if not self.warm:
+                        # one eager step on a side stream first (lazy set-up that must not happen under capture: weight packing,
+                        # function attributes, allocator pools); the state it changes is put back
+                        keep = (self.z.X.clone(), self.z.E.clone(), None if self.eig is None else self.eig.state.clone())
+                        s = torch.cuda.Stream()
+                        s.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(s):
+                            self._body(t)
+                        torch.cuda.current_stream().wait_stream(s)
+                        self.z.X.copy_(keep[0]); self.z.E.copy_(keep[1])
+                        if self.eig is not None:
+                            self.eig.state.copy_(keep[2])
+                        self.warm = True
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool):
+                        self._body(t)
+                    self.graphs[t] = g
+                g.replay()
+        return self.z

@@ -14,11 +14,13 @@ from . import graph, helpers
 class SamplingMixin:
     @torch.no_grad()
     def sample_one_batch(self, device=None, n_samples=None, data=None, get_chains=False, get_true_rxns=False,
-                         inpaint_node_idx=None, inpaint_edge_idx=None, noise_fn=None, chain_seeds=None):
+                         inpaint_node_idx=None, inpaint_edge_idx=None, noise_fn=None, chain_seeds=None, record_chains=None):
         """noise_fn(call_index, shape) -> Exp(1) tensor makes the draws a function of explicit noise (tests); the
         call order equals the reference's multinomial call order (X then E; limit draw first).
         chain_seeds (B,) int64: per-chain counter-based noise (helpers.counter_exp_noise) -- every chain's draws depend on its
-        own seed only, so sharded runs give the same samples under any rank layout (diffalign_amd/distributed.py)."""
+        own seed only, so sharded runs give the same samples under any rank layout (diffalign_amd/distributed.py).
+        record_chains=False: keep the return structure of get_chains=True but record no intermediate states (sample_for_condition reads
+        element 0 only); then no step leaves the fused path, and small batches replay their steps as HIP graphs (graphs.GraphedChain)."""
         assert data is not None, 'diffalign_amd samples conditionally: `data` (the dense condition) is required'
         assert self.cfg.test.with_denoising
         dense_data = data
@@ -77,6 +79,9 @@ class SamplingMixin:
         if self.cfg.neuralnet.extra_features and self.extra_features_fn is None and self.cfg.diffusion.denoiser == 'neuralnet':
             from .extra_features import EigCache
             eig_cache = EigCache.from_free_masks(masks[1], node_mask)
+        # noise on the padded slots of one eigenvector feature (extra_features.py:189: it only keeps 0 from becoming the mode there): drawn
+        # once per chain instead of once per step
+        pad_noise = torch.randn(B, n, device=device) if eig_cache is not None else None
         T_eval = self.cfg.diffusion.diffusion_steps_eval
         assert self.T % T_eval == 0, 'diffusion_steps_eval should be divisible by diffusion_steps'
         eval_step_size = self.T // T_eval
@@ -91,12 +96,23 @@ class SamplingMixin:
         # step numbers and the y input of every step, laid out once (a fill, a cast and a multiply per step otherwise)
         all_t = torch.arange(T_eval + 1, device=device)[:, None, None].expand(-1, B, 1).contiguous()
         all_y = all_t.float() * eval_step_size
-        for t_int in range(T_eval, 0, -1):
+        recording = get_chains if record_chains is None else (get_chains and record_chains)
+        from . import graphs
+        if (not recording and not guided and chain_seeds is not None and self._net().supports_fused_step() and not self._net()._differentiable()
+                and graphs.chain_graphs_wanted(B, n)):
+            gc = graphs.GraphedChain.get(self, dense_data, masks, pos_encodings, temps, fix_nodes, fix_edges, eig_cache is not None, calls[0])
+            gc.load(dense_data, masks, pos_encodings, fix_nodes, fix_edges, chain_seeds, z_t, eig_cache, pad_noise)
+            zg = gc.run()
+            z_t.X, z_t.E = zg.X.clone(), zg.E.clone()
+            T_loop = range(0)
+        else:
+            T_loop = range(T_eval, 0, -1)
+        for t_int in T_loop:
             t_array = all_t[t_int]
-            z_t.eig_cache = eig_cache                                      # read by compute_extra_data; not carried by get_new_object
+            z_t.eig_cache, z_t.pad_noise = eig_cache, pad_noise            # read by compute_extra_data; not carried by get_new_object
             z_t.y = all_y[t_int]                                           # raw train-scale step index (sampling.py:76)
             s_int = t_int - 1
-            record = get_chains and (s_int % log_every_t == 0 or s_int == self.T - 1)
+            record = recording and (s_int % log_every_t == 0 or s_int == self.T - 1)
             if not record and not guided:                                  # the whole step as one call (fused where the model allows)
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
                                                 orig=dense_data, node_masks=masks, t_int=t_int, **nz(step=True))

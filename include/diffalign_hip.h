@@ -17,7 +17,7 @@ extern "C" {
 #endif
 
 /* Version of this header's contracts; a binding built against another version must refuse the library (diffalign_amd/_lib.py does).
- * 3: da_init added, da_edge_out_g / da_edge_out_finish removed.  2: da_y_film / da_y_update / da_y_update_film / da_y_pre expect the
+ * 3: da_init, the bf16-storage training kernels (da_attn_core_*_bf16, da_linear_wgrad_mixed) and the fused residual blocks (da_res_ln_*, da_relu_dropout*) added, da_edge_out_g / da_edge_out_finish removed.  2: da_y_film / da_y_update / da_y_update_film / da_y_pre expect the
  * y-chain weights k-major, i.e. transposed to (in, out); da_edge_layer_stats puts its ticket word back to zero itself. */
 #define DA_ABI_VERSION 3
 int da_abi_version(void);
@@ -165,6 +165,38 @@ long long da_attn_core_bwd_workspace(int B, int n, int dx);
 long long da_linear_wgrad_workspace(long long R, int in_features, int out_features);
 int da_linear_wgrad(const float* X, const float* dY, float* dW, float* db, void* workspace, long long workspace_bytes, long long R,
                     int in_features, int out_features, void* stream);
+/* Mixed-precision training (the reference trains under fp16 autocast: diffusion/diffusion_abstract.py:181-183, training/helpers.py:139-141):
+ * the same three kernels with the per-pair streams in bf16 STORAGE -- E1, E2, Z / dZ, dE1, dE2 of the attention core, X and / or dY of the
+ * weight gradient (x_bf16 / dy_bf16 != 0) -- and fp32 arithmetic; per-node and per-graph tensors stay fp32.  The attention pair: dx % 4 == 0
+ * with dx / 4 dividing 256, workspace as da_attn_core_bwd_workspace. */
+int da_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, const void* E1, const void* E2, const uint8_t* node_mask,
+                          const float* ye1, const float* ye2, float qscale, void* Z, float* wV, float* smax, float* ssum, int B, int n, int dx,
+                          void* stream);
+int da_attn_core_bwd_bf16(const float* Q, const float* K, const float* V, const void* E1, const void* E2, const uint8_t* node_mask,
+                          const float* ye2, float qscale, const float* wV, const float* smax, const float* ssum, const void* dZ, const float* dwV,
+                          float* dQ, float* dK, float* dV, void* dE1, void* dE2, float* dye1, float* dye2, void* workspace,
+                          long long workspace_bytes, int B, int n, int dx, void* stream);
+int da_linear_wgrad_mixed(const void* X, int x_bf16, const void* dY, int dy_bf16, float* dW, float* db, void* workspace,
+                          long long workspace_bytes, long long R, int in_features, int out_features, void* stream);
+/* Fused residual block of XEyTransformerLayer (layers.py:341-359: norm(res + dropout(branch))) for the training step, and its
+ * backward.  s = res + dropout_p(mask(u)); out = LayerNorm(s) * gamma + beta (eps 1e-5); out_bf16 (may be NULL): out again in bf16, the
+ * operand of the next bf16 GEMM.  u / d_u are fp32 or bf16 (u_bf16).  mask_mode 0: none; 1: row r is zeroed unless node_mask[r]
+ * (rows = B n); 2: row (b n + i) n + j is zeroed unless node_mask[b,i] and node_mask[b,j] (rows = B n n; `newE * e_mask`, layers.py:262).
+ * Dropout stores no mask: the keep bits are a hash of (element, *seed, salt) -- seed is read on the device, so a captured graph draws
+ * fresh masks per replay -- and the backward regenerates them from the same (seed, salt, p); p = 0 is the reference's eval arithmetic
+ * exactly.  The backward takes the gradient of out and / or out_bf16 (either may be NULL), returns d_res = d s, d_u (may be NULL),
+ * dgamma, dbeta; workspace: da_res_ln_bwd_workspace(D) bytes.  D in {16, 32, 64, 128, 256}; fp32 operands 16-byte, bf16 8-byte aligned. */
+int da_res_ln_fwd(const float* res, const void* u, int u_bf16, const uint8_t* node_mask, int mask_mode, int n, const float* gamma,
+                  const float* beta, const long long* seed, int salt, float p, float* s_out, float* out, void* out_bf16, long long rows,
+                  int D, void* stream);
+long long da_res_ln_bwd_workspace(int D);
+int da_res_ln_bwd(const float* s, const float* gamma, const float* d_out, const void* d_out_bf16, const uint8_t* node_mask, int mask_mode, int n,
+                  const long long* seed, int salt, float p, float* d_res, void* d_u, int u_bf16, float* dgamma, float* dbeta,
+                  void* workspace, long long workspace_bytes, long long rows, int D, void* stream);
+/* dropout_p(relu(h)) in place between the two Linears of a feed-forward branch (layers.py:349-357), fp32 or bf16 storage, numel % 4 == 0;
+ * backward: dx = dy / (1 - p) where the stored result is non-zero, else 0 (no mask kept; dx may alias dy). */
+int da_relu_dropout(void* h, int is_bf16, long long numel, const long long* seed, int salt, float p, void* stream);
+int da_relu_dropout_bwd(const void* h, const void* dy, void* dx, int is_bf16, long long numel, float p, void* stream);
 /* LayerNorm backward (eps 1e-5; layers.py:341-359): s (rows,D) = the normalised input, dy the gradient of gamma * xhat + beta ->
  * ds (rows,D), dgamma (D), dbeta (D).  D in {32, 64, 128, 256}; s, dy, ds 16-byte aligned; workspace: 8 * 1024 * D bytes for the
  * per-workgroup partial sums of dgamma / dbeta (folded in workgroup order: deterministic). */

@@ -184,3 +184,57 @@ def test_config2_shape_100_steps_100_samples_one_condition():
     assert torch.equal(a.E.cpu()[:, s:, :], ecl[s:, :].expand(n_samples, -1, -1))
     assert bool((a.X.cpu()[:, ~true['node_mask'][0]] == 0).all())
     assert len({tuple(r.tolist()) for r in a.X.cpu()[:, :s]}) > 1         # chains are not copies of each other
+
+
+def test_graphed_chain_equals_eager_chain():
+    """graphs.GraphedChain: every reverse step of a small batch replayed as a HIP graph (three-stream arrangement captured, extra
+    features with the eigensolver's fixed-block cache inside, counter noise, inpainting) gives the eager loop's samples bit for bit;
+    a second chain of the same shape reuses the graphs (nothing is captured again) and a chain of another shape gets its own."""
+    from diffalign_amd.diffusion_rxn import DiscreteDenoisingDiffusionRxn
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd.distributed import chain_seed
+    from diffalign_amd import synthetic as S, graphs
+    from tests.golden.common import extra_info
+    dims = dict(n_layers=2, hidden_dims={'dx': 256, 'de': 64, 'dy': 64, 'n_head': 8, 'dim_ffX': 256, 'dim_ffE': 128, 'dim_ffy': 128},
+                hidden_mlp_dims={'X': 256, 'E': 128, 'y': 128})
+    torch.manual_seed(0)
+    cfg = make_cfg(dims, T_=20, T_eval=10, extra=True)
+    cfg.neuralnet.pos_encoding_type = 'smiles_pos_enc'
+    cfg.train.log_every_t = 3
+    info = make_info()
+    for k, v in vars(extra_info(ns)).items():
+        setattr(info, k, v)
+    model = DiscreteDenoisingDiffusionRxn(cfg, info, device=D).eval()
+    old = graphs.CHAIN_GRAPHS
+    try:
+        for case, (n, P, B, inp) in enumerate([(40, None, 5, True), (40, None, 5, False), (33, 8, 3, False)]):
+            true = S.make_reaction_batch(B, n, seed=30 + case, P=P)
+            seeds = torch.tensor([chain_seed(2, 10 * case + g) for g in range(B)], dtype=torch.int64)
+            kw = dict(inpaint_node_idx=[[0, 1]] + [[] for _ in range(B - 1)] if inp else None,
+                      inpaint_edge_idx=[[[0, 1]]] + [[] for _ in range(B - 1)] if inp else None, chain_seeds=seeds)
+            res = {}
+            for mode in ('0', '1'):
+                graphs.CHAIN_GRAPHS = mode
+                torch.manual_seed(77)                                       # the per-chain noise on padded slots
+                cond = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+                res[mode] = model.sample_for_condition(dense_data=cond, n_samples=1, **kw)
+            assert torch.equal(res['0'].X, res['1'].X) and torch.equal(res['0'].E, res['1'].E), case
+            assert not torch.equal(res['1'].X[0], res['1'].X[1])
+        cache = model._chain_graphs
+        assert len(cache) == 3 and all(len(g.graphs) == 10 for g in cache.values())
+        graphs.CHAIN_GRAPHS = '1'
+        first = next(iter(cache.values()))
+        ids = [id(g) for g in first.graphs.values()]
+        true = S.make_reaction_batch(5, 40, seed=99, P=None)
+        cond = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+        seeds = torch.arange(5, dtype=torch.int64) + 1000
+        torch.manual_seed(5)
+        a = model.sample_for_condition(dense_data=cond, n_samples=1, inpaint_node_idx=[[2, 3]] + [[]] * 4, inpaint_edge_idx=[[[1, 2]]] + [[]] * 4, chain_seeds=seeds)
+        assert [id(g) for g in first.graphs.values()] == ids              # replayed, not re-captured
+        graphs.CHAIN_GRAPHS = '0'
+        torch.manual_seed(5)
+        cond = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+        b = model.sample_for_condition(dense_data=cond, n_samples=1, inpaint_node_idx=[[2, 3]] + [[]] * 4, inpaint_edge_idx=[[[1, 2]]] + [[]] * 4, chain_seeds=seeds)
+        assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E)
+    finally:
+        graphs.CHAIN_GRAPHS = old
