@@ -157,7 +157,8 @@ class GraphedChain:
         if self.fix_edges is not None:
             self.fix_edges.copy_(fix_edges)
         self.seeds.copy_(seeds)
-        self.pad_noise.copy_(pad_noise)
+        if pad_noise is not None:                            # drawn per chain only when the extra features' eigensolver runs
+            self.pad_noise.copy_(pad_noise)
         self.z.X.copy_(z_start.X); self.z.E.copy_(z_start.E)
         for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
             if getattr(self.z, name) is not None:
@@ -174,7 +175,7 @@ class GraphedChain:
     def _body(self, t):
         from . import graph
         m, z = self.model, self.z
-        z.eig_cache, z.pad_noise = self.eig, self.pad_noise
+        z.eig_cache, z.pad_noise = self.eig, (self.pad_noise if self.eig is not None else None)
         z.y = self.all_y[t]
         zsX, zsE, _ = m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
                                      orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
