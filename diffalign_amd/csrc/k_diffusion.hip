@@ -27,6 +27,27 @@ __global__ void k_mask_dense_E(float* E, const uint8_t* nm, int B, int n, int d)
   for (int c = 0; c < d; ++c) { float v = e[c] * m; e[c] = v; s += v; }
   if (s == 0.f) e[0] = 1.f;
 }
+// the same for feature widths that are a multiple of 4 with d / 4 lanes dividing a wave (hidden features: d = 64 -> 16 lanes per pair,
+// 16-byte accesses; the per-thread row walk above moves 4 bytes per lane and instruction: 372 us against 45 us at B = 16, n = 140)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_mask_dense_E4(float* E, const uint8_t* nm, int B, int n) {
+  const size_t tot = (size_t)B * n * n;
+  const int lr = threadIdx.x % LPR;
+  for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR; p < (tot + 63) / 64 * 64; p += (size_t)gridDim.x * blockDim.x / LPR) {
+    const bool ok = p < tot;
+    const size_t pc = ok ? p : tot - 1;
+    const int j = pc % n; const int i = (pc / n) % n; const int b = pc / ((size_t)n * n);
+    const float m = (nm[b * n + i] && nm[b * n + j] && i != j) ? 1.f : 0.f;
+    float4* e = reinterpret_cast<float4*>(E + pc * (4 * LPR)) + lr;
+    float4 v = *e;
+    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (s == 0.f && lr == 0) v.x = 1.f;
+    if (ok) *e = v;
+  }
+}
 // collapse=True: argmax then zero masked (utils/placeholder.py:90-94)
 __global__ void k_collapse_X(const float* X, const uint8_t* nm, int64_t* out, int rows, int d) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,7 +411,10 @@ int da_mask_dense(float* X, float* E, const uint8_t* node_mask, int B, int n, in
   hipStream_t s = (hipStream_t)stream;
   if (B == 0 || n == 0) return DA_OK;
   if (X && dx > 0) k_mask_dense_X<<<g1((size_t)B * n, 256), 256, 0, s>>>(X, node_mask, B * n, dx);
-  if (E && de > 0) k_mask_dense_E<<<g1((size_t)B * n * n, 256), 256, 0, s>>>(E, node_mask, B, n, de);
+  if (E && de == 64 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
+    size_t g = ((size_t)B * n * n * 16 + 255) / 256; if (g > 8192) g = 8192;
+    k_mask_dense_E4<16><<<(unsigned)g, 256, 0, s>>>(E, node_mask, B, n);
+  } else if (E && de > 0) k_mask_dense_E<<<g1((size_t)B * n * n, 256), 256, 0, s>>>(E, node_mask, B, n, de);
   DA_CHECK_LAUNCH("da_mask_dense");
   return DA_OK;
 }

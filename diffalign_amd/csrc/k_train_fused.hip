@@ -148,21 +148,32 @@ __global__ void __launch_bounds__(256) k_res_ln_bwd(const float* __restrict__ s,
     pb[(size_t)blockIdx.x * D + c] = (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]);
   }
 }
-// d gamma / d beta: the G partial rows summed in order (deterministic); thread = one of the 2 D outputs, 8-way unrolled loads
+// d gamma / d beta: the G partial rows folded in a fixed order (deterministic).  Workgroup = 32 of the 2 D outputs x 8 groups of
+// partial rows; a thread sums its group's rows sixteen loads at a time, the 8 group sums are added in group order through LDS
+// (one thread per output walking all G rows took 30 us a call, 52 calls a step).
 __global__ void __launch_bounds__(256) k_col_fold(const float* __restrict__ pg, const float* __restrict__ pb, float* __restrict__ dg,
                                                   float* __restrict__ db, int G, int D) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * D) return;
+  __shared__ float s_p[8][32];
+  const int ol = threadIdx.x & 31, gg = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + ol;
+  const bool live = t < 2 * D;
   const float* src = t < D ? pg + t : pb + (t - D);
+  const int per = (G + 7) / 8, g0 = gg * per, g1 = min(G, g0 + per);
   float sum = 0.f;
-  for (int g = 0; g < G; g += 8) {
-    float v[8];
+  if (live)
+    for (int g = g0; g < g1; g += 16) {
+      float v[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = g + q < G ? src[(size_t)(g + q) * D] : 0.f;
+      for (int q = 0; q < 16; ++q) v[q] = g + q < g1 ? src[(size_t)(g + q) * D] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sum += v[q];
+      for (int q = 0; q < 16; ++q) sum += v[q];
+    }
+  s_p[gg][ol] = sum;
+  __syncthreads();
+  if (gg == 0 && live) {
+    for (int k = 1; k < 8; ++k) sum += s_p[k][ol];
+    if (t < D) dg[t] = sum; else db[t - D] = sum;
   }
-  if (t < D) dg[t] = sum; else db[t - D] = sum;
 }
 
 // ReLU + dropout in place, 8 elements (two quads) per lane for bf16, 4 for fp32
@@ -265,7 +276,7 @@ int da_res_ln_bwd(const float* s, const float* gamma, const float* d_out, const 
     break;
   switch (D) { BWD(16) BWD(32) BWD(64) BWD(128) BWD(256) }
 #undef BWD
-  k_col_fold<<<(2 * D + 255) / 256, 256, 0, st>>>(pg, pb, dgamma, dbeta, (int)g, D);
+  k_col_fold<<<(2 * D + 31) / 32, 256, 0, st>>>(pg, pb, dgamma, dbeta, (int)g, D);
   DA_CHECK_LAUNCH("da_res_ln_bwd");
   return DA_OK;
 }

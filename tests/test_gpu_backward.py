@@ -281,14 +281,15 @@ def test_full_width_layers_gradients_vs_oracle(precision, fused):
     print(f'worst full-width parameter-gradient error ({precision})', worst)
 
 
-def test_hidden_mask_gradient():
+@pytest.mark.parametrize('de', [8, 64])       # 64: the hidden width, which takes the 16-byte-per-lane form of the mask kernel
+def test_hidden_mask_gradient(de):
     from diffalign_amd.autograd_ops import MaskDense
     from diffalign_amd import _lib as L
     g = torch.Generator().manual_seed(9)
     nm = ragged_mask(3, 12, g)
-    X, E = torch.randn(3, 12, 16, generator=g).requires_grad_(), torch.randn(3, 12, 12, 8, generator=g).requires_grad_()
+    X, E = torch.randn(3, 12, 16, generator=g).requires_grad_(), torch.randn(3, 12, 12, de, generator=g).requires_grad_()
     rX, rE = O.mask_dense(X, E, nm)
-    gX, gE = torch.randn(3, 12, 16, generator=g), torch.randn(3, 12, 12, 8, generator=g)
+    gX, gE = torch.randn(3, 12, 16, generator=g), torch.randn(3, 12, 12, de, generator=g)
     ((rX * gX).sum() + (rE * gE).sum()).backward()
     Xd, Ed = X.detach().to(D).requires_grad_(), E.detach().to(D).requires_grad_()
     oX, oE = MaskDense.apply(Xd, Ed, L.as_u8(nm.to(D)))
