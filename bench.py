@@ -105,6 +105,55 @@ def cpu_baseline(seconds_budget=25.0):
                       f'B={B} graph at n={n} (the graph size of the GPU workload) in {dt:.1f}s'}
 
 
+def train_rooflines(B, n, dev, bf16, dx=256, de=64):
+    """HBM rooflines of the training step's two largest own kernels, timed live with HIP events on tensors of the step's shapes
+    (inside the captured step a launch cannot be bracketed): the attention core's backward and the weight gradient of a per-pair
+    Linear (e_mul / e_add, 64 -> 256).  Algorithmic bytes = every operand the kernel must read or write once."""
+    from diffalign_amd import _lib as L
+    g = torch.Generator(device=dev).manual_seed(0)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    eb = 2 if bf16 else 4
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    nm = torch.ones(B, n, dtype=torch.uint8, device=dev)
+    Q, K, V, ye1, ye2 = r(B, n, dx), r(B, n, dx), r(B, n, dx), r(B, dx), r(B, dx)
+    E1, E2 = r(B, n, n, dx).to(dt), r(B, n, n, dx).to(dt)
+    Z = torch.empty_like(E1); wV = torch.empty_like(Q); sm = torch.empty_like(Q); sl = torch.empty_like(Q)
+    lib = L.lib()
+    fwd, bwd = (lib.da_attn_core_fwd_bf16, lib.da_attn_core_bwd_bf16) if bf16 else (lib.da_attn_core_fwd, lib.da_attn_core_bwd)
+    S = L.stream()
+    L.check(fwd(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm), L.ptr(ye1), L.ptr(ye2), 0.177, L.ptr(Z), L.ptr(wV), L.ptr(sm),
+                L.ptr(sl), B, n, dx, S), 'attn fwd')
+    dZ, dwV = r(B, n, n, dx).to(dt), r(B, n, dx)
+    ws = torch.empty(int(lib.da_attn_core_bwd_workspace(B, n, dx)), dtype=torch.uint8, device=dev)
+    dQ, dK, dV, dE1, dE2, d1, d2 = (torch.empty_like(t) for t in (Q, Q, Q, E1, E1, ye1, ye1))
+    f_bwd = lambda: L.check(bwd(L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(E1), L.ptr(E2), L.ptr(nm), L.ptr(ye2), 0.177, L.ptr(wV), L.ptr(sm), L.ptr(sl),
+                                L.ptr(dZ), L.ptr(dwV), L.ptr(dQ), L.ptr(dK), L.ptr(dV), L.ptr(dE1), L.ptr(dE2), L.ptr(d1), L.ptr(d2), L.ptr(ws),
+                                ws.numel(), B, n, dx, S), 'attn bwd')
+    R = B * n * n
+    x, dy = r(R, de).to(dt), r(R, dx).to(dt)
+    dW, db = torch.empty(dx, de, device=dev), torch.empty(dx, device=dev)
+    ws2 = torch.empty(int(lib.da_linear_wgrad_workspace(R, de, dx)), dtype=torch.uint8, device=dev)
+    f_wg = lambda: L.check(lib.da_linear_wgrad_mixed(L.ptr(x), int(bf16), L.ptr(dy), int(bf16), L.ptr(dW), L.ptr(db), L.ptr(ws2), ws2.numel(), R, de,
+                                                     dx, S), 'wgrad')
+
+    def timed(fn, reps=20):
+        for _ in range(3): fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record()
+        for _ in range(reps): fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    out = []
+    for name, fn, nbytes, what in (
+            ('k_attn_bwd4 (+ k_attn_fold)', f_bwd, R * dx * eb * 5, 'E1, E2, dZ read, dE1, dE2 written once per pair-channel'),
+            ('k_wgrad_partial<64,256> (+ k_wgrad_fold)', f_wg, R * (de + dx) * eb, 'X and dY rows read once')):
+        ms = timed(fn)
+        out.append({'kernel': name, 'bound': 'hbm', 'achieved': nbytes / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': nbytes / ms / 1e6 / 8000.0,
+                    'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes, 'storage': 'bf16' if bf16 else 'f32', 'what': what, 'traffic': None})
+    return out
+
+
 def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None):
     """BASELINE.json configs[3]: data-parallel training steps of the align_absorbing denoiser (9 layers, 8.18M parameters, dropout
     0.2 as configs/neuralnet/default.yaml) on synthetic USPTO-like graphs; every rank holds its own batch, the only collective is the
@@ -163,6 +212,7 @@ def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None)
                                                  f'batch {B}/GPU padded to n={n} (USPTO-like sizes), dropout 0.2, AdamW(amsgrad), extra features and '
                                                  'Laplacian position encodings computed on the device inside the step' , 'global_batch': B * world,
                                      'parallelism': f'dp{world} (one flat-gradient all-reduce per step)', 'hip_graph': train_graph},
+                          'roofline': train_rooflines(B, n, dev, args.train_precision == 'bf16'),
                           'loss_first_last': [float(losses[0]), float(losses[-1])],
                           'peak_hbm_GB': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if dist is not None:

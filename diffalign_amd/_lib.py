@@ -38,7 +38,6 @@ SIGNATURES = {
     'da_elbo_rows': 'i:ippppppppppippppfppiiiip',
     'da_masked_sums': 'i:pppppiip',
     'da_ce_grad': 'i:pppppppffppiiiip',
-    'da_skip_grad': 'i:pppipippiiiip',
     'da_attn_core_fwd': 'i:ppppppppfppppiiip',
     'da_attn_core_bwd': 'i:pppppppfpppppppppppppqiiip', 'da_attn_core_bwd_workspace': 'q:iii',
     'da_attn_core_fwd_bf16': 'i:ppppppppfppppiiip', 'da_attn_core_bwd_bf16': 'i:pppppppfpppppppppppppqiiip',

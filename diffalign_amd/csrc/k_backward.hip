@@ -154,12 +154,21 @@ __global__ void __launch_bounds__(256) k_attn_fwd4(const float* __restrict__ Q, 
   const bool mi = nm[row] != 0;
   const f32x4 q = ld4(Q + row * dx + c) * qscale, f1 = ld4(ye1 + (size_t)b * dx + c), f2 = ld4(ye2 + (size_t)b * dx + c) + 1.f;
   f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l = {0.f, 0.f, 0.f, 0.f}, a = l;
+  // every operand of a key is loaded unconditionally (a masked pair's E1 / E2 are dropped by a select AFTER the load: a load behind an
+  // exec-masked branch gets its own s_waitcnt vmcnt(0) and the four streams of a key are fetched one after the other), and the next
+  // key's operands are in flight while this one is evaluated
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto off_of = [&](int j) { return (row * n + min(j, n - 1)) * dx + c; };
+  auto kj_of = [&](int j) { return ((size_t)b * n + min(j, n - 1)) * dx + c; };
+  f32x4 e1n = ld4(E1 + off_of(js)), e2n = ld4(E2 + off_of(js)), kn = ld4(K + kj_of(js)), vn = ld4(V + kj_of(js));
+  uint8_t mjn = nm[(size_t)b * n + min(js, n - 1)];
   for (int j = js; j < n; j += JS) {
-    const size_t kj = ((size_t)b * n + j) * dx + c, off = (row * n + j) * dx + c;
-    const bool pm = mi && nm[(size_t)b * n + j] != 0;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 e1 = pm ? ld4(E1 + off) : zero, e2 = pm ? ld4(E2 + off) : zero, v = ld4(V + kj);
-    const f32x4 y = (q * ld4(K + kj)) * (e1 + 1.f) + e2;
+    const size_t off = (row * n + j) * dx + c;
+    const bool pm = mi && mjn != 0;
+    const f32x4 e1 = pm ? e1n : zero, e2 = pm ? e2n : zero, v = vn, k = kn;
+    e1n = ld4(E1 + off_of(j + JS)); e2n = ld4(E2 + off_of(j + JS)); kn = ld4(K + kj_of(j + JS)); vn = ld4(V + kj_of(j + JS));
+    mjn = nm[(size_t)b * n + min(j + JS, n - 1)];
+    const f32x4 y = (q * k) * (e1 + 1.f) + e2;
     st4(Z + off, f1 + f2 * y);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -222,17 +231,42 @@ __global__ void __launch_bounds__(256) k_attn_bwd4(const float* __restrict__ Q, 
     q[t] = ld4(Q + row); m[t] = ld4(smax + row); inv_l[t] = 1.f / ld4(ssum + row); g[t] = ld4(dwV + row); D[t] = g[t] * ld4(wV + row);
     dq[t] = zero; mi[t] = t < ni && nm[(size_t)b * n + i0 + t] != 0;
   }
+  // The 3 IB row operands of a key are loaded up front and unconditionally (rows past the block clamped, masked pairs dropped by a
+  // select after the load): behind exec-masked branches every one of them had its own s_waitcnt vmcnt(0).  With bf16 storage (half the
+  // registers per operand) the NEXT key's operands are in flight while this one is evaluated.
+  constexpr bool AHEAD = sizeof(TE) == 2;
+  f32x4 e1n[IB], e2n[IB], dzn[IB], kn, vn;
+  uint8_t mjn = 0;
+  auto fetch = [&](int j, f32x4 (&e1)[IB], f32x4 (&e2)[IB], f32x4 (&dz)[IB], f32x4& kk, f32x4& vv, uint8_t& mj) {
+    const int jc = min(j, n - 1);
+    const size_t kj = ((size_t)b * n + jc) * dx + c;
+    kk = ld4(K + kj); vv = ld4(V + kj); mj = nm[(size_t)b * n + jc];
+#pragma unroll
+    for (int t = 0; t < IB; ++t) {
+      const size_t off = (((size_t)b * n + i0 + min(t, ni - 1)) * n + jc) * dx + c;
+      e1[t] = ld4(E1 + off); e2[t] = ld4(E2 + off); dz[t] = ld4(dZ + off);
+    }
+  };
+  if constexpr (AHEAD) fetch(js, e1n, e2n, dzn, kn, vn, mjn);
   for (int j = js; j < n; j += JS) {
-    const size_t kj = ((size_t)b * n + j) * dx + c;
-    const bool mj = nm[(size_t)b * n + j] != 0;
-    const f32x4 k = ld4(K + kj), v = ld4(V + kj);
+    f32x4 e1r[IB], e2r[IB], dzr[IB], k, v;
+    uint8_t mjb;
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int t = 0; t < IB; ++t) { e1r[t] = e1n[t]; e2r[t] = e2n[t]; dzr[t] = dzn[t]; }
+      k = kn; v = vn; mjb = mjn;
+      fetch(j + JS, e1n, e2n, dzn, kn, vn, mjn);
+    } else {
+      fetch(j, e1r, e2r, dzr, k, v, mjb);
+    }
+    const bool mj = mjb != 0;
     f32x4 dk = zero, dv = zero;
 #pragma unroll
     for (int t = 0; t < IB; ++t) {
       if (t < ni) {
         const size_t off = (((size_t)b * n + i0 + t) * n + j) * dx + c;
         const bool pm = mi[t] && mj;
-        const f32x4 e1 = (pm ? ld4(E1 + off) : zero) + 1.f, e2 = pm ? ld4(E2 + off) : zero, dz = ld4(dZ + off);
+        const f32x4 e1 = (pm ? e1r[t] : zero) + 1.f, e2 = pm ? e2r[t] : zero, dz = dzr[t];
         const f32x4 qk = (q[t] * k) * qscale;
         const f32x4 y = qk * e1 + e2;
         f32x4 attn;

@@ -40,41 +40,6 @@ __global__ void __launch_bounds__(256) k_ce_grad(const float* __restrict__ tr, c
   for (int k = 0; k < K; ++k) grad[r + k] = w * (x[k] * inv - (k == cls ? 1.f : 0.f));
 }
 
-// Gradients of the product->reactant skip scalings (transformer_model_with_y.py:684-704) per graph:
-//   out[b][0] = sum over aligned nodes r of <gX[r], X_in[src[r]][:kx]> + sum over aligned pairs (i,j) of <gE[i,j], E_in[src i, src j][:ke]>
-//   out[b][1] = sum over non-aligned pairs of gE[i,j][0]
-__global__ void __launch_bounds__(256) k_skip_grad(const float* __restrict__ gX, const float* __restrict__ gE,
-                                                   const float* __restrict__ Xin, int dxin, const float* __restrict__ Ein, int dein,
-                                                   const int* __restrict__ src, float* __restrict__ out, int n, int kx, int ke) {
-  __shared__ double red[2][256];
-  const int b = blockIdx.x;
-  double a0 = 0.0, a1 = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int si = src[b * n + i];
-    if (si < 0) continue;
-    const float* g = gX + ((size_t)b * n + i) * kx; const float* x = Xin + ((size_t)b * n + si) * dxin;
-    for (int k = 0; k < kx; ++k) a0 += (double)g[k] * x[k];
-  }
-  for (int p = threadIdx.x; p < n * n; p += 256) {
-    const int i = p / n, j = p - i * n;
-    const int si = src[b * n + i], sj = src[b * n + j];
-    const float* g = gE + ((size_t)b * n * n + p) * ke;
-    if (si >= 0 && sj >= 0) {
-      const float* e = Ein + (((size_t)b * n + si) * n + sj) * dein;
-      for (int k = 0; k < ke; ++k) a0 += (double)g[k] * e[k];
-    } else {
-      a1 += g[0];
-    }
-  }
-  red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-    __syncthreads();
-  }
-  if (threadIdx.x < 2) out[b * 2 + threadIdx.x] = (float)red[threadIdx.x][0];
-}
-
 template <int K, bool IS_E>
 static void launch_ce_grad(const float* tr, const float* lg, const uint8_t* fm, const float* sums, float scale, float* grad, int B,
                            int n, hipStream_t s) {
@@ -100,16 +65,6 @@ int da_ce_grad(const float* true_X, const float* true_E, const float* logits_X, 
   if (grad_X) { CE_DISPATCH(kx, false, true_X, logits_X, mask_x, sums, weight_X, grad_X, B, n, s) }
   if (grad_E) { CE_DISPATCH(ke, true, true_E, logits_E, mask_e, sums, weight_E, grad_E, B, n, s) }
   DA_CHECK_LAUNCH("da_ce_grad");
-  return DA_OK;
-}
-
-int da_skip_grad(const float* grad_X, const float* grad_E, const float* X_in, int dx_in, const float* E_in, int de_in, const int* src,
-                 float* out, int B, int n, int kx, int ke, void* stream) {
-  DA_CHECK_ARG(src != nullptr && out != nullptr, "da_skip_grad: src / out are null");
-  DA_CHECK_ARG(kx <= dx_in && ke <= de_in, "da_skip_grad: class counts exceed the input widths");
-  if (B == 0) return DA_OK;
-  k_skip_grad<<<B, 256, 0, (hipStream_t)stream>>>(grad_X, grad_E, X_in, dx_in, E_in, de_in, src, out, n, kx, ke);
-  DA_CHECK_LAUNCH("da_skip_grad");
   return DA_OK;
 }
 

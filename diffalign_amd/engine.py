@@ -377,9 +377,8 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
 
 
 def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None,
-                  use_skip=False, save: Optional[dict] = None, step: Optional[dict] = None, edge_skip_uniform=False, align_src=None):
+                  use_skip=False, step: Optional[dict] = None, edge_skip_uniform=False, align_src=None):
     """GraphTransformerWithY[AtomMapPosEmb].forward (neuralnet/transformer_model_with_y.py:74-111, 620-713).
-    `save`: dict that receives what the output-stage backward needs (diffalign_amd/training.py).
     `step`: the reverse step fused behind the output stage (helpers.ReverseStep.ctx: z_t, transition tables, noise, masks): the edge
     half is drawn inside the output kernel (da_edge_out_sample) and the edge logits are not materialised (Eo is None); the node half runs behind the node output path.  The drawn state lands in step['zs_X'], step['zs_E'].
     `align_src` (B,n) int32: the skip connection's product index per node when it is not da_align_index's (alignment_type='old').
@@ -522,6 +521,4 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                                       _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')
     if xout_done is not None:
         main.wait_event(xout_done)
-    if save is not None:
-        save.update(X_in=X, E_in=E, X_hidden=Xh, out_X_hidden=h1, src=src, node_mask=nm)
     return Xo, Eo, yh

@@ -5,8 +5,7 @@
 every parameter; `optim.FlatAdamW` (fused AdamW with amsgrad over one flat buffer) and `distributed.allreduce_flat_gradient`
 complete the step (`train_one_step`).  Loss values and gradient norms are pinned to the reference's own `loss.backward()`
 (tests/golden/chain_elbo_tiny.npz), every parameter's gradient to autograd on the oracle.
-`model.eval()` or no_grad: the same call evaluates the loss VALUES through the fused bf16 inference path (no graph), and
-`training_backward_output_stage` gives the hand-derived last-stage gradients of round 1.
+`model.eval()` or no_grad: the same call evaluates the loss VALUES through the fused bf16 inference path (no graph).
 """
 from __future__ import annotations
 
@@ -43,8 +42,7 @@ class TrainingMixin:
                       z_t: Optional[PlaceHolder] = None, pos_encodings=None, want_terms: bool = True,
                       uncond_draw: Optional[torch.Tensor] = None):
         """diffusion_abstract.py:134-225.  `data`: dense PlaceHolder on the device (the reference's graph.to_dense is the data
-        loader's side).  Returns (loss_X, loss_E, loss) as the reference does -- values, without an autograd graph; the
-        context the backward needs stays in self._train_ctx.  t_int / noise / z_t fix the reference's random draws;
+        loader's side).  Returns (loss_X, loss_E, loss) as the reference does.  t_int / noise / z_t fix the reference's random draws;
         uncond_draw (B,) in [0,1) stands for the `torch.rand(bs)` of classifier-free guidance (:163)."""
         d = self.cfg.diffusion
         dense_data = data
@@ -72,7 +70,6 @@ class TrainingMixin:
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings,   # pos_encodings: precomputed (they depend on the condition only)
                                 use_pos_encoding_if_applicable=use_pos)
             loss = DiffusionLoss.apply(pred.X, pred.E, self, dense_data, z_keep, node_masks, loss_kind)
-            self._train_ctx = None
             loss_X = loss_E = torch.zeros((1,))
             if loss_kind == 'ce' and want_terms:      # the per-element CE terms the reference also returns (a boolean gather: a host sync)
                 with torch.no_grad():
@@ -80,14 +77,8 @@ class TrainingMixin:
                     mx, me = node_masks[0].bool(), node_masks[1].bool()
                     loss_X, loss_E = -rX[mx], -rE[me[:, :, None] & me[:, None, :]]
             return loss_X, loss_E, loss
-        saved: Dict[str, torch.Tensor] = {}
-        net = self._net() if hasattr(self, '_net') else self.model
-        net._saved = saved
-        try:
-            with torch.no_grad():
-                pred = self.forward(z_t=z_t, use_pos_encoding_if_applicable=use_pos)                          # :181-185
-        finally:
-            net._saved = None
+        with torch.no_grad():
+            pred = self.forward(z_t=z_t, use_pos_encoding_if_applicable=use_pos)                              # :181-185
         lam = d.lambda_train[0]
         loss_X = loss_E = torch.zeros((1,))
         if loss_kind in ('ce', 'vbce'):
@@ -104,7 +95,6 @@ class TrainingMixin:
             loss = self.elbo_batch_quick(dense_data, pred=pred, z_t=z_keep, lambda_E=lam) + d.ce_lambda * ce  # :221-222
         else:
             raise ValueError(f'Unknown loss {loss_kind}')
-        self._train_ctx = dict(pred=pred, data=dense_data, node_masks=node_masks, saved=saved, loss_kind=loss_kind, lam=lam)
         return loss_X, loss_E, loss
 
     def _drop_condition(self, dense_data: PlaceHolder, z_t: PlaceHolder, uncond_draw: Optional[torch.Tensor]):
@@ -149,35 +139,6 @@ class TrainingMixin:
         if update_ema and getattr(self, 'ema', None) is not None:     # (a captured step leaves it to its caller: the decay is host state)
             self.ema.update()                                                                                 # training/helpers.py:143-144
         return loss.detach()
-
-    def training_backward_output_stage(self) -> Dict[str, torch.Tensor]:
-        """First stage of `loss.backward()` for train.loss == 'ce': gradients with respect to the logits and to the output
-        stage's last parameters.  Returns {'pred.X', 'pred.E', 'mlp_out_X.2.weight', 'mlp_out_X.2.bias', 'skip_scaling',
-        'skip_scaling_2'} (the skip entries only with the product->reactant skip connection).  The backward through
-        mlp_out_E, the transformer layers and the input stage is not built."""
-        ctx = getattr(self, '_train_ctx', None)
-        if ctx is None:
-            raise RuntimeError('training_backward_output_stage: call training_step first')
-        if ctx['loss_kind'] != 'ce':
-            raise NotImplementedError("only train.loss == 'ce' has a backward stage (d L_t / d logits of 'vb' is not built)")
-        d = self.cfg.diffusion
-        pred, data, saved = ctx['pred'], ctx['data'], ctx['saved']
-        gX, gE = ce_grad(pred, data, ctx['node_masks'], ctx['lam'], bool(d.diffuse_nodes), bool(d.diffuse_edges))
-        B, n, kx = gX.shape
-        ke = gE.shape[-1]
-        g2 = gX.reshape(B * n, kx)
-        out = {'pred.X': gX, 'pred.E': gE,
-               'mlp_out_X.2.weight': g2.t() @ saved['out_X_hidden'],       # (kx, hidden): a plain library GEMM
-               'mlp_out_X.2.bias': g2.sum(0)}
-        if saved.get('src') is not None:
-            part = torch.empty(B, 2, device=gX.device)
-            X_in, E_in = saved['X_in'], saved['E_in']
-            L.check(L.lib().da_skip_grad(L.ptr(gX), L.ptr(gE), L.ptr(X_in), C.c_int(X_in.shape[-1]), L.ptr(E_in), C.c_int(E_in.shape[-1]),
-                                         L.ptr(saved['src']), L.ptr(part), C.c_int(B), C.c_int(n), C.c_int(kx), C.c_int(ke),
-                                         L.stream()), 'da_skip_grad')
-            tot = part.double().sum(0).float()
-            out['skip_scaling'], out['skip_scaling_2'] = tot[0:1], tot[1:2]
-        return out
 
 
 def train_one_epoch(model, batches, optimizer, scheduler=None, *, epoch: int = 0, losses: Optional[list] = None, group=None, shuffle: bool = True):

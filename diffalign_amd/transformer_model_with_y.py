@@ -36,7 +36,6 @@ class _DenoiserBase(nn.Module):
         self._packed = None
         self._packed_key = None
         self._plist = None      # list(self.parameters()), dropped when the module tree is rebuilt by _apply (.to(), .float(), ...)
-        self._saved = None      # dict filled by engine.model_forward for the output-stage backward (training.py)
 
     def _pack(self, device):
         # re-pack when any parameter was rewritten (torch's version counters), moved (storage pointers) or stepped behind torch's back
@@ -79,7 +78,7 @@ class GraphTransformerWithY(_DenoiserBase):
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask) + (node_mask,)
         pm = self._pack(X.device)
-        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, save=self._saved, step=step)
+        Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, step=step)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask
 
@@ -122,7 +121,7 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
             from .train_forward import align_index
             src = align_index(atom_map_numbers, mol_assignments, 'old')
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
-                                          use_skip=self.p_to_r_skip_connection, save=self._saved, step=step,
+                                          use_skip=self.p_to_r_skip_connection, step=step,
                                           edge_skip_uniform=self.input_alignment, align_src=src)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
         return Xo, Eo, yo, node_mask

@@ -17,7 +17,7 @@ extern "C" {
 #endif
 
 /* Version of this header's contracts; a binding built against another version must refuse the library (diffalign_amd/_lib.py does).
- * 3: da_init, the bf16-storage training kernels (da_attn_core_*_bf16, da_linear_wgrad_mixed) and the fused residual blocks (da_res_ln_*, da_relu_dropout*) added, da_edge_out_g / da_edge_out_finish removed.  2: da_y_film / da_y_update / da_y_update_film / da_y_pre expect the
+ * 3: da_init, the bf16-storage training kernels (da_attn_core_*_bf16, da_linear_wgrad_mixed) and the fused residual blocks (da_res_ln_*, da_relu_dropout*) added, da_edge_out_g / da_edge_out_finish / da_skip_grad removed.  2: da_y_film / da_y_update / da_y_update_film / da_y_pre expect the
  * y-chain weights k-major, i.e. transposed to (in, out); da_edge_layer_stats puts its ticket word back to zero itself. */
 #define DA_ABI_VERSION 3
 int da_abi_version(void);
@@ -132,11 +132,6 @@ int da_masked_sums(const float* rows_X, const float* rows_E, const uint8_t* mask
 int da_ce_grad(const float* true_X, const float* true_E, const float* logits_X, const float* logits_E, const uint8_t* mask_x,
                const uint8_t* mask_e, const float* sums, float weight_X, float weight_E, float* grad_X, float* grad_E, int B, int n,
                int kx, int ke, void* stream);
-/* Gradients of skip_scaling and skip_scaling_2 (neuralnet/transformer_model_with_y.py:684-704, alignment 'correct') per
- * graph: out (B,2); out[b][0] = sum over aligned nodes of <grad_X, X_in[src]> + sum over aligned pairs of
- * <grad_E, E_in[src i, src j]>, out[b][1] = sum over non-aligned pairs of grad_E[..., 0].  src from da_align_index. */
-int da_skip_grad(const float* grad_X, const float* grad_E, const float* X_in, int dx_in, const float* E_in, int de_in, const int* src,
-                 float* out, int B, int n, int kx, int ke, void* stream);
 
 /* ---- training path: the non-GEMM pieces of the fp32 forward / backward (diffusion_abstract.py:134-225, training/helpers.py:139-142).
  * Every nn.Linear of the training forward and both of its backward products are library GEMMs under torch.autograd; these entry
