@@ -401,7 +401,7 @@ struct OutSampleArgs {
   const float* orig; const uint8_t* me; float* zs;
 };
 template <int DE, int HE, bool SAMPLE>
-__global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
+__global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
                                                         const uint4* __restrict__ blob, const int* __restrict__ src,
                                                         const float* __restrict__ s1p, const float* __restrict__ s2p,
                                                         float* __restrict__ E_o, int n, int Ke, OutSampleArgs sa) {
@@ -416,7 +416,6 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
   float* sRow = sB + 32 * 32 * 8;                       // [wave][32 * 8]: one output row of tile (it, jt) per wave
   const bool vec4 = ((n * Ke) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_o) & 15) == 0;   // rows of E_o start 16-byte aligned
   for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += OT_THR) sW[t] = blob[t];
-  __syncthreads();
   const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * C::KS1 * 64;
   const float* sP = reinterpret_cast<const float*>(sW + C::OUT_FR * 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -439,6 +438,18 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
       sFree[w][threadIdx.x & 31] = (q < n && sa.me) ? sa.me[gb + q] : 1;
     }
   }
+  __syncthreads();                                         // weights, sSrc, sNm, sFree
+  // SAMPLE: a pair whose endpoints are not both free to diffuse takes the condition's value (apply_mask), so its logits are never
+  // looked at: rows i / j that are not free are neither loaded nor evaluated, and a tile pair without a free row on either side goes
+  // straight to the copy of the condition.  With the reaction's product side fixed that is most of the tensor (73 % of the pairs
+  // of the benchmark's graphs); the free pairs' logits, draws and noise indices are what they were.
+  bool tile_live = true;
+  if constexpr (SAMPLE) {
+    const unsigned long long fb = __ballot(sFree[lane >> 5][lane & 31] != 0);
+    tile_live = (fb & 0xffffffffull) != 0 && (fb >> 32) != 0;
+  }
+  auto live_i = [&](int ri) { return !SAMPLE || sFree[0][ri] != 0; };
+  auto live_j = [&](int rj) { return !SAMPLE || sFree[1][rj] != 0; };
   uint4 cur[DE / 16], nxt[DE / 16];
   float ein_c[4], ein_n[4];                             // E_in[row, pair, 4h .. 4h+3] of the current / next row
   auto load_ein = [&](int row, int col, float (&d)[4]) {
@@ -448,15 +459,26 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
   };
   {
     const int i = it * 32 + r, ic = i < n ? i : n - 1;
-    if (jt * 32 + wave < n) { edge_row_load<DE>(E_h + ((gb + jt * 32 + wave) * n + ic) * DE, h, cur); load_ein(jt * 32 + wave, ic, ein_c); }
+    if (tile_live && jt * 32 + wave < n && live_j(wave)) { edge_row_load<DE>(E_h + ((gb + jt * 32 + wave) * n + ic) * DE, h, cur); load_ein(jt * 32 + wave, ic, ein_c); }
   }
-  for (int rj = wave; rj < 32; rj += OT_NW) {               // phase 1 (the next row's loads are issued before this row's MFMAs)
+  for (int rj = wave; rj < 32 && tile_live; rj += OT_NW) {   // phase 1 (the next row's loads are issued before this row's MFMAs)
     const int j = jt * 32 + rj;
     if (j >= n) break;
     const int i = it * 32 + r; const bool iv = i < n; const int ic = iv ? i : n - 1;
-    if (rj + OT_NW < 32 && j + OT_NW < n) { edge_row_load<DE>(E_h + ((gb + j + OT_NW) * n + ic) * DE, h, nxt); load_ein(j + OT_NW, ic, ein_n); }
+    if (rj + OT_NW < 32 && j + OT_NW < n && live_j(rj + OT_NW)) { edge_row_load<DE>(E_h + ((gb + j + OT_NW) * n + ic) * DE, h, nxt); load_ein(j + OT_NW, ic, ein_n); }
+    if (!live_j(rj)) {                                       // wave-uniform: nothing of this row is ever read
+#pragma unroll
+      for (int u = 0; u < DE / 16; ++u) cur[u] = nxt[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ein_c[e] = ein_n[e];
+      continue;
+    }
     f32x16 o;
+#ifdef EXP_OT_NOMFMA
+    o = splat16(__builtin_bit_cast(float, cur[0].x));
+#else
     mlp_out_chain_regs<DE, HE>(cur, h, lane, sW0, sW1, sP, o);
+#endif
     if (iv) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const int c = 4 * h + e; if (c < Ke) sB[(rj * 32 + r) * 8 + c] = o[e] + ein_c[e]; }
@@ -466,7 +488,7 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) ein_c[e] = ein_n[e];
   }
-  __syncthreads();                                         // sSrc, sB complete
+  __syncthreads();                                         // sB complete
   const int jA = jt * 32 + r; const bool jv = jA < n; const int jc = jv ? jA : n - 1;
   const int sjA = sSrc[1][r];
   float aln_c[4], aln_n[4];                             // E_in[src i, src j, 4h .. 4h+3] where the pair is aligned, else 0
@@ -477,19 +499,30 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = (al && 4 * h + e < Ke) ? p[e] : 0.f;
   };
-  if (it * 32 + wave < n) {
+  if (tile_live && it * 32 + wave < n && live_i(wave)) {
     edge_row_load<DE>(E_h + ((gb + it * 32 + wave) * n + jc) * DE, h, cur); load_ein(it * 32 + wave, jc, ein_c);
     if (src) load_aln(wave, aln_c);
   }
-  for (int ri = wave; ri < 32; ri += OT_NW) {               // phase 2
+  for (int ri = wave; ri < 32 && tile_live; ri += OT_NW) {   // phase 2
     const int i = it * 32 + ri;
     if (i >= n) break;
-    if (ri + OT_NW < 32 && i + OT_NW < n) {
+    if (ri + OT_NW < 32 && i + OT_NW < n && live_i(ri + OT_NW)) {
       edge_row_load<DE>(E_h + ((gb + i + OT_NW) * n + jc) * DE, h, nxt); load_ein(i + OT_NW, jc, ein_n);
       if (src) load_aln(ri + OT_NW, aln_n);
     }
+    if (!live_i(ri)) {
+#pragma unroll
+      for (int u = 0; u < DE / 16; ++u) cur[u] = nxt[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ein_c[e] = ein_n[e]; aln_c[e] = aln_n[e]; }
+      continue;
+    }
     f32x16 o;
+#ifdef EXP_OT_NOMFMA
+    o = splat16(__builtin_bit_cast(float, cur[0].x));
+#else
     mlp_out_chain_regs<DE, HE>(cur, h, lane, sW0, sW1, sP, o);
+#endif
     float* srow = sRow + wave * 32 * 8;
     if (jv) {
       const bool aligned = sSrc[0][ri] >= 0 && sjA >= 0;
@@ -523,10 +556,11 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
   if constexpr (SAMPLE) {
     __syncthreads();                                      // the tile's logits are complete in sB ([column j][row i][8])
     const size_t base = (size_t)b * n * n;
-    for (int t = threadIdx.x; t < 32 * 32; t += OT_THR) { // pair (row ri, column cj): k_posterior_E_tiles' evaluation of it
+    for (int t = threadIdx.x; t < 32 * 32 && tile_live; t += OT_THR) { // pair (row ri, column cj): k_posterior_E_tiles' evaluation of it
       const int ri = t >> 5, cj = t & 31, i = it * 32 + ri, j = jt * 32 + cj;
       int c = 0;
-      if (i < j && j < n && sNm[0][ri] && sNm[1][cj]) {
+#ifndef EXP_OT_NODRAW
+      if (i < j && j < n && sNm[0][ri] && sNm[1][cj] && sFree[0][ri] && sFree[1][cj]) {
         const size_t pr = base + (size_t)i * n + j;
         float lg[OT_K], u[OT_K], q[OT_K];
         const float* lp = sB + (cj * 32 + ri) * 8;
@@ -544,25 +578,40 @@ __global__ void __launch_bounds__(OT_THR, 2) k_edge_out_tiles(const bf16_t* __re
         }
         c = race<OT_K>(u, q);
       }
+#endif
       sCls[ri][cj] = (uint8_t)c;
     }
     __syncthreads();
-    constexpr int W = 32 * OT_K;
-    for (int t = threadIdx.x; t < 32 * W; t += OT_THR) {  // tile (it, jt), rows i
-      const int ri = t / W, o = t - ri * W, cj = o / OT_K, k = o - cj * OT_K, i = it * 32 + ri, j = jt * 32 + cj;
-      if (i >= n || j >= n) continue;
-      const int c = i < j ? sCls[ri][cj] : (i > j ? sCls[cj][ri] : 0);   // i > j only inside a diagonal tile
-      const size_t q = (base + (size_t)i * n + j) * OT_K + k;
-      sa.zs[q] = (sFree[0][ri] && sFree[1][cj]) ? (k == c ? 1.f : 0.f) : sa.orig[q];
-    }
-    if (jt != it)
-      for (int t = threadIdx.x; t < 32 * W; t += OT_THR) { // tile (jt, it), rows j
-        const int rj = t / W, o = t - rj * W, ci = o / OT_K, k = o - ci * OT_K, j = jt * 32 + rj, i = it * 32 + ci;
-        if (i >= n || j >= n) continue;
-        const int c = sCls[ci][rj];
-        const size_t q = (base + (size_t)j * n + i) * OT_K + k;
-        sa.zs[q] = (sFree[0][ci] && sFree[1][rj]) ? (k == c ? 1.f : 0.f) : sa.orig[q];
+    // Both mirrored tiles of z_s, row-wise (a row's 32 * K floats are contiguous).  The condition's values for pairs that are not free
+    // are gathered seven elements per thread at a time and the stores follow the batch: with one element per trip every trip waited
+    // for its own load (14 dependent round trips per tile, about half of this kernel's time at B = 64, n = 300).
+    constexpr int W = 32 * OT_K, UNW = 7;
+    const float* og = sa.orig ? sa.orig : sa.zt;               // without a condition every pair is free and the value read is not used
+    auto write_tile = [&](const bool mirrored) {
+      for (int t0 = threadIdx.x; t0 < 32 * W; t0 += OT_THR * UNW) {
+        float ov[UNW]; bool ok[UNW], fr[UNW], hot[UNW]; size_t qq[UNW];
+#pragma unroll
+        for (int u = 0; u < UNW; ++u) {
+          const int t = min(t0 + u * OT_THR, 32 * W - 1);
+          const int rr = t / W, o = t - rr * W, cx = o / OT_K, k = o - cx * OT_K;
+          const int ri = mirrored ? cx : rr, cj = mirrored ? rr : cx;       // position inside tile (it, jt): row i, column j
+          const int i = it * 32 + ri, j = jt * 32 + cj;
+          ok[u] = t0 + u * OT_THR < 32 * W && i < n && j < n;
+          const int c = mirrored ? sCls[ri][cj] : (i < j ? sCls[ri][cj] : (i > j ? sCls[cj][ri] : 0));   // i > j only inside a diagonal tile
+          fr[u] = sFree[0][ri] && sFree[1][cj];
+          hot[u] = k == c;
+          qq[u] = (base + (mirrored ? (size_t)j * n + i : (size_t)i * n + j)) * OT_K + k;
+          ov[u] = og[ok[u] ? qq[u] : base * OT_K];           // unconditional (a predicated load would make every later wait a vmcnt(0))
+        }
+#pragma unroll
+        for (int u = 0; u < UNW; ++u)
+          if (ok[u]) sa.zs[qq[u]] = fr[u] ? (hot[u] ? 1.f : 0.f) : ov[u];
       }
+    };
+#ifndef EXP_OT_NOWRITE
+    write_tile(false);
+    if (jt != it) write_tile(true);
+#endif
     return;
   }
   if (jt == it) return;
