@@ -206,6 +206,84 @@ __global__ void k_posterior_X(const float* logits, const float* zt, const uint8_
   }
 }
 
+// nodes, K > 16 classes: 32 lanes per (b,i), lane k owns class k.  One thread per node walks K x K quotients one after the other
+// (841 divisions for the 29 atom classes: 75 - 130 us for a few thousand nodes, all latency); here a lane does its own column's K.
+// Every value is produced by the same operations in the same order as posterior_elem / race do (the softmax sums and the total are
+// accumulated in class order, by every lane alike or through shuffles): same bits.  A draw-only call skips nodes that are not free
+// to diffuse -- their row is the condition's.
+template <int K>
+__global__ void __launch_bounds__(256) k_posterior_X_lanes(const float* logits, const float* zt, const uint8_t* nm, const float* Qt,
+                                                           const float* Qsb, const float* Qtb, float temp, const float* noise,
+                                                           const float* orig, const uint8_t* mx, float* prob_out, float* zs_out, int B, int n) {
+  static_assert(K <= 32, "one class per lane of a half wave");
+  extern __shared__ float sQ[];  // 3*K*K
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < 3 * K * K; t += blockDim.x) {
+    int w = t / (K * K), o = t % (K * K);
+    const float* src = w == 0 ? Qt : (w == 1 ? Qsb : Qtb);
+    sQ[t] = src[(size_t)b * K * K + o];
+  }
+  __syncthreads();
+  const float* sQt = sQ; const float* sQsb = sQ + K * K; const float* sQtb = sQ + 2 * K * K;
+  const int kl = threadIdx.x & 31, k = min(kl, K - 1), half = (threadIdx.x & 63) & 32;
+  const int i = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+  const bool inside = i < n;
+  const size_t r = (size_t)b * n + min(i, n - 1);
+  const bool valid = nm[r] != 0;
+  const bool free_ = mx ? mx[r] != 0 : true;
+  if (!prob_out && !free_) {                               // (uniform over the 32 lanes of the node)
+    if (inside && kl < K) zs_out[r * K + k] = orig[r * K + k];
+    return;
+  }
+  const int xt = onehot_argmax<K>(zt + r * K);
+  float l[K];
+  float m1 = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < K; ++c) { l[c] = logits[r * K + c]; m1 = fmaxf(m1, l[c]); }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < K; ++c) s += expf(l[c] - m1);
+  const float lse = m1 + logf(s);
+  float m2 = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < K; ++c) { l[c] = (l[c] - lse) * temp; m2 = fmaxf(m2, l[c]); }
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < K; ++c) { l[c] = expf(l[c] - m2); s2 += l[c]; }
+  float u = 0.f;
+  const float a = sQt[k * K + xt];
+#pragma unroll
+  for (int k0 = 0; k0 < K; ++k0) {
+    const float ph = l[k0] / s2;
+    float d = sQtb[k0 * K + xt];
+    if (d == 0.f) d = 1e-6f;
+    u += ph * ((a * sQsb[k0 * K + k]) / d);
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < K; ++c) tot += __shfl(u, half + c);
+  if (tot == 0.f) {
+    u = 1e-5f;
+    tot = 0.f;
+#pragma unroll
+    for (int c = 0; c < K; ++c) tot += 1e-5f;
+  }
+  u = u / tot;
+  if (!valid) u = k == 0 ? 1.f : 0.f;                       // prob_s.mask(): zero row -> encode_no_element -> class 0
+  const bool wr = inside && kl < K;
+  if (prob_out && wr) prob_out[r * K + k] = u;
+  if (zs_out) {
+    int cls = 0;
+    if (valid) {
+      const float v = u / noise[r * K + k];
+      float bv = __shfl(v, half);
+#pragma unroll
+      for (int c = 1; c < K; ++c) { const float vc = __shfl(v, half + c); if (vc > bv) { bv = vc; cls = c; } }
+    }
+    if (wr) zs_out[r * K + k] = free_ ? (k == cls ? 1.f : 0.f) : orig[r * K + k];
+  }
+}
+
 // edges: one thread per ordered pair (b,i,j); the draw of the unordered pair comes from (min,max)
 template <int K>
 __global__ void k_posterior_E(const float* logits, const float* zt, const uint8_t* nm, const float* Qt, const float* Qsb,
@@ -376,6 +454,11 @@ template <int K>
 static int launch_post_X(const float* logits, const float* zt, const uint8_t* nm, const float* Qt, const float* Qsb,
                          const float* Qtb, float temp, const float* noise, const float* orig, const uint8_t* mx,
                          float* prob, float* zs, int B, int n, hipStream_t s) {
+  if constexpr (K > 16 && K <= 32) {
+    k_posterior_X_lanes<K><<<dim3(cdiv(n, 8), B), 256, 3 * K * K * sizeof(float), s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, mx,
+                                                                                    prob, zs, B, n);
+    return 0;
+  }
   dim3 grid(cdiv(n, 128), B);
   k_posterior_X<K><<<grid, 128, 3 * K * K * sizeof(float), s>>>(logits, zt, nm, Qt, Qsb, Qtb, temp, noise, orig, mx, prob,
                                                                zs, B, n);
