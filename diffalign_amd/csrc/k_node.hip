@@ -60,16 +60,32 @@ __global__ void __launch_bounds__(256, 2) k_linear(const float* __restrict__ A, 
       const int kb = 16 * s + 8 * h;
       float av[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) av[j] = (kb + j < K) ? ap[kb + j] : 0.f;
+      for (int j = 0; j < 8; ++j) av[j] = ap[min(kb + j, K - 1)];         // unconditional; zeroed below
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (kb + j >= K) av[j] = 0.f;
       const uint4 au = {pack_bf16(av[0], av[1]), pack_bf16(av[2], av[3]), pack_bf16(av[4], av[5]), pack_bf16(av[6], av[7])};
       af[s] = frag_from_u4(au);
     }
   }
+  // Every load of this kernel is unconditional (clamped index, value selected afterwards) and issued with its batch: a load inside a
+  // branch gets a wait of its own -- the 16 row-mask bytes were 16 round trips, and a bias load inside the column guard put an
+  // s_waitcnt vmcnt(0) in front of each of a tile's 16 stores, which also waited for the NEXT tile's prefetched weights (the double
+  // buffer overlapped nothing): 47 -> 20 us for 7,200 rows x 256 -> 256.
   uint8_t rm[16];
+  {
+    const uint8_t* mp = rowmask ? rowmask : reinterpret_cast<const uint8_t*>(bias ? (const void*)bias : (const void*)A);   // any valid address
+    const int mmax = rowmask ? M - 1 : 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rm[i] = rowmask ? rowmask[min(m0 + crow(i, h), M - 1)] : (uint8_t)1;
+    for (int i = 0; i < 16; ++i) rm[i] = mp[min(m0 + crow(i, h), mmax)];
+    if (!rowmask) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rm[i] = 1;
+    }
+  }
   const int NTall = (N + 31) / 32;
-  auto load_w = [&](uint4 (&wf)[KSMAX], int t) {
+  const float* bp = bias ? bias : A;                   // (valid address; the value is dropped when there is no bias)
+  const int bmax = bias ? N - 1 : 0;
+  auto load_w = [&](uint4 (&wf)[KSMAX], float& bv, int t) {
     const uint4* wp = W + ((size_t)min(nt0 + t, NTall - 1) * KS) * 64 + lane;
 #pragma unroll
 #ifdef EXP_LIN_NOW
@@ -77,14 +93,15 @@ __global__ void __launch_bounds__(256, 2) k_linear(const float* __restrict__ A, 
 #else
     for (int s = 0; s < KSMAX; ++s) wf[s] = wp[min(s, KS - 1) * 64];
 #endif
+    bv = bp[min((nt0 + t) * 32 + r, bmax)];
   };
-  auto tile = [&](const uint4 (&wf)[KSMAX], int t) {
+  auto tile = [&](const uint4 (&wf)[KSMAX], float bvl, int t) {
     f32x16 acc = splat16(0.f);
 #pragma unroll
     for (int s = 0; s < KSMAX; ++s) acc = mfma32(af[s], frag_from_u4(wf[s]), acc);
     const int col = (nt0 + t) * 32 + r;
     if (col < N) {
-      const float bv = bias ? bias[col] : 0.f;
+      const float bv = bias ? bvl : 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = m0 + crow(i, h);
@@ -101,12 +118,13 @@ __global__ void __launch_bounds__(256, 2) k_linear(const float* __restrict__ A, 
     }
   };
   uint4 wA[KSMAX], wB[KSMAX];
-  load_w(wA, 0);
+  float bA, bB;
+  load_w(wA, bA, 0);
   for (int t = 0; t < ntiles; t += 2) {
-    load_w(wB, t + 1);
-    tile(wA, t);
-    load_w(wA, t + 2);
-    if (t + 1 < ntiles) tile(wB, t + 1);
+    load_w(wB, bB, t + 1);
+    tile(wA, bA, t);
+    load_w(wA, bA, t + 2);
+    if (t + 1 < ntiles) tile(wB, bB, t + 1);
   }
 }
 
@@ -169,7 +187,10 @@ __global__ void k_x_out_finish(const float* lin, int ldl, const float* Xin, int 
 
 // alignment gather index (semantics of transformer_model_with_y.py:506-555, alignment_type='correct'):
 // src[b,r] = product node with the same atom-map number as reactant-side node r, else -1.  One block per graph.
-__global__ void k_align_index(const int64_t* am, const int64_t* mol, int* src, int n) {
+// The graph's atom-map numbers and a product flag per node are staged in LDS first (LDS_N > 0): the search loop of a node then walks
+// LDS instead of issuing up to n dependent global loads (38 -> ~8 us at B = 64, n = 300).
+__global__ void k_align_index(const int64_t* am, const int64_t* mol, int* src, int n, int lds_n) {
+  extern __shared__ long long s_am[];                 // [lds_n] atom-map number of product nodes, 0 elsewhere
   const int b = blockIdx.x;
   __shared__ int s_prod;
   if (threadIdx.x == 0) s_prod = INT_MIN;
@@ -179,12 +200,21 @@ __global__ void k_align_index(const int64_t* am, const int64_t* mol, int* src, i
   atomicMax(&s_prod, mx);
   __syncthreads();
   const long long prod = s_prod;
+  if (lds_n >= n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_am[i] = mol[(size_t)b * n + i] == prod ? am[(size_t)b * n + i] : 0;
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int res = -1;
     const long long a = am[(size_t)b * n + i];
     if (a > 0 && mol[(size_t)b * n + i] != prod) {
-      for (int j = 0; j < n; ++j)
-        if (mol[(size_t)b * n + j] == prod && am[(size_t)b * n + j] == a) { res = j; break; }
+      if (lds_n >= n) {
+        for (int j = 0; j < n; ++j)
+          if (s_am[j] == a) { res = j; break; }       // (a > 0, so a product node whose number is 0 never matches)
+      } else {
+        for (int j = 0; j < n; ++j)
+          if (mol[(size_t)b * n + j] == prod && am[(size_t)b * n + j] == a) { res = j; break; }
+      }
     }
     src[(size_t)b * n + i] = res;
   }
@@ -530,7 +560,8 @@ int da_x_out_finish(const float* lin, int ldl, const float* X_in, int dx_in, con
 
 int da_align_index(const int64_t* atom_map_numbers, const int64_t* mol_assignments, int* src, int B, int n, void* stream) {
   if (B == 0 || n == 0) return DA_OK;
-  k_align_index<<<B, 256, 0, (hipStream_t)stream>>>(atom_map_numbers, mol_assignments, src, n);
+  const int lds_n = n <= 6144 ? n : 0;             // 8 bytes per node in LDS; larger graphs search global memory
+  k_align_index<<<B, 256, (size_t)lds_n * sizeof(long long), (hipStream_t)stream>>>(atom_map_numbers, mol_assignments, src, n, lds_n);
   DA_CHECK_LAUNCH("da_align_index");
   return DA_OK;
 }
