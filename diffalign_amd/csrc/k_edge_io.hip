@@ -198,8 +198,29 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
   const float* base = E_in + (size_t)b * n * n * de_in;
   const bool vec = ((n * de_in) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_in) & 15) == 0;
   for (int t = threadIdx.x; t < (de_in + 2) * Q; t += 256) sT[t] = T[t];
+  // Tile loads: all of a thread's (up to 8) 16-byte pieces are requested before the first is used, from clamped addresses; with one
+  // guarded load per trip a tile cost seven dependent HBM round trips, and its mirror seven more (103 -> 60 us at B = 64, n = 300).
+  constexpr int UN_T = 8;                              // 32 rows x 8 de_in float4 / 256 threads, de_in <= 8
   {
     const int vw = min(32, n - jt * 32) * de_in;       // valid floats of a tile row
+    if (vec && 32 * W4 <= UN_T * 256) {                // (vec: n de_in % 4 == 0, hence vw % 4 == 0 and every row start is 16-byte aligned)
+      float4 v[UN_T];
+#pragma unroll
+      for (int u = 0; u < UN_T; ++u) {
+        const int t = min((int)threadIdx.x + u * 256, 32 * W4 - 1);
+        const int ri = t / W4, o = (t - ri * W4) * 4;
+        v[u] = *reinterpret_cast<const float4*>(base + ((size_t)min(it * 32 + ri, n - 1) * n + jt * 32) * de_in + max(min(o, vw - 4), 0));
+      }
+#pragma unroll
+      for (int u = 0; u < UN_T; ++u) {
+        const int t = threadIdx.x + u * 256;
+        if (t < 32 * W4) {
+          const int ri = t / W4, o = (t - ri * W4) * 4;
+          const bool ok = it * 32 + ri < n && o < vw;
+          *reinterpret_cast<float4*>(sA + ri * W + o) = ok ? v[u] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else
     for (int t = threadIdx.x; t < 32 * W4; t += 256) {
       const int ri = t / W4, o = (t - ri * W4) * 4, i = it * 32 + ri;
       float4 v = {0.f, 0.f, 0.f, 0.f};
@@ -226,6 +247,28 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
   bool bad = false;
   {
     const int vw = min(32, n - it * 32) * de_in;
+    if (vec && 32 * W4 <= UN_T * 256) {                // tile (jt, it): rows j, columns i; same batched loads
+      float4 q[UN_T];
+#pragma unroll
+      for (int u = 0; u < UN_T; ++u) {
+        const int t = min((int)threadIdx.x + u * 256, 32 * W4 - 1);
+        const int rj = t / W4, o = (t - rj * W4) * 4;
+        q[u] = *reinterpret_cast<const float4*>(base + ((size_t)min(jt * 32 + rj, n - 1) * n + it * 32) * de_in + max(min(o, vw - 4), 0));
+      }
+#pragma unroll
+      for (int u = 0; u < UN_T; ++u) {
+        const int t = threadIdx.x + u * 256;
+        const int rj = t / W4, o = (t - rj * W4) * 4;
+        if (t < 32 * W4 && jt * 32 + rj < n && o < vw) {
+          const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ci = (o + k) / de_in, c = (o + k) - ci * de_in;
+            bad = bad || (v[k] != sA[ci * W + rj * de_in + c]);
+          }
+        }
+      }
+    } else
     for (int t = threadIdx.x; t < 32 * W4; t += 256) {  // tile (jt, it): rows j, columns i
       const int rj = t / W4, o = (t - rj * W4) * 4, j = jt * 32 + rj;
       if (j >= n) continue;
