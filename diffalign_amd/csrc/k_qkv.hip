@@ -36,10 +36,12 @@ __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X
   }
   // rows of this lane's accumulator registers: key/query row 32jt + crow(i,h); dead rows (j >= n) and masked nodes give 0
   float rm[16];
+  {
+    uint8_t mb[16];                                    // loaded unconditionally, as one batch (16 guarded loads were 16 round trips)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int j = 32 * jt + crow(i, h);
-    rm[i] = (j < n && mask[(size_t)b * n + min(j, n - 1)]) ? 1.f : 0.f;
+    for (int i = 0; i < 16; ++i) mb[i] = mask[(size_t)b * n + min(32 * jt + crow(i, h), n - 1)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rm[i] = (32 * jt + crow(i, h) < n && mb[i]) ? 1.f : 0.f;
   }
   auto load_w = [&](uint4 (&wf)[KS], int t) {
     const uint4* wp = W + ((size_t)min(t, 3 * NCB - 1) * KS) * 64 + lane;

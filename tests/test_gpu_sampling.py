@@ -27,7 +27,7 @@ def make_cfg(dims, T_=10, T_eval=10, extra=False):
                            pos_encoding_type='laplacian_pos_enc', p_to_r_skip_connection=True, p_to_r_init=1.0,
                            alignment_type='correct', input_alignment=False, increase_y_dim_for_multigpu=True, use_ema=False,
                            pos_emb_permutations=0),
-              train=ns(loss='ce'), test=ns(with_denoising=True, loss_0_repeat=1))
+              train=ns(loss='ce', log_every_t=1), test=ns(with_denoising=True, loss_0_repeat=1))
 
 
 def make_info():
@@ -64,6 +64,46 @@ def test_chain_config0_against_reference_golden():
     # measured: nodes 1.0000, edges >= 0.998 (a handful of near-tie edge draws flip under bf16 logits and propagate)
     assert ax >= 0.98 and ae >= 0.99, (ax, ae)
     assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
+
+
+def test_temperature_chain_and_recorded_chains_against_reference_golden():
+    """tests/golden/chain_temp_tiny.npz: the reference's sample_one_batch(get_chains=True) at temperature_scaling_node = 0.7 /
+    _edge = 1.4 with log_every_t = 3 (make_golden_r3.py).  The temperature enters the posterior of every step (da_posterior_sample's
+    temp arguments) and the recorded pred_0 chain (softmax(T log_softmax(logits)), sampling.py:82,118-129).  Same structure of the
+    recorded chains; at the first logged step (the state is still the reference's own: the limit draw is bit-exact) probabilities within
+    the bf16 tolerance; final chain agreement statistical as for configs[0] (the oracle reproduces this chain bit for bit)."""
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    z, zt = load('chain_elbo_tiny'), load('chain_temp_tiny')
+    cfg = make_cfg(tiny_dims())
+    cfg.diffusion.temperature_scaling_node, cfg.diffusion.temperature_scaling_edge = (float(v) for v in zt['temps'])
+    cfg.train.log_every_t = int(zt['log_every_t'])
+    model = DiscreteDenoisingDiffusion(cfg, make_info(), device=D).eval()
+    model.model.load_state_dict(weights_of(z))
+    am = T(z['am'])
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=am), 64, seed=73).to(D)
+    model.pos_encodings_fn = lambda zt_: pos
+    data = PlaceHolder(X=F.one_hot(T(z['true_X']), KX).float().to(D), E=F.one_hot(T(z['true_E']), KE).float().to(D),
+                       y=torch.zeros(4, 1, device=D), node_mask=T(z['node_mask']).to(D), atom_map_numbers=am.to(D),
+                       mol_assignments=T(z['mol']).to(D))
+    final, samples, probs, preds = model.sample_one_batch(data=data, get_chains=True, noise_fn=lambda c, shp: counter_noise(shp, c))
+    assert [t for t, _ in samples] == [int(t) for t in zt['sample_steps']]
+    assert [s for s, _ in probs] == [int(s) for s in zt['logged_steps']] == [s for s, _ in preds]
+    # first logged step (s = 9): z_T is the reference's (bit-exact limit draw + apply_mask), so only the bf16 logits differ
+    assert np.array_equal(samples[0][1].X.cpu().numpy(), zt['sample10_X']) and np.array_equal(samples[0][1].E.cpu().numpy(), zt['sample10_E'])
+    for name, got, tol in (('prob9_X', probs[0][1].X, 3e-2), ('prob9_E', probs[0][1].E, 3e-2), ('pred9_X', preds[0][1].X, 3e-2),
+                           ('pred9_E', preds[0][1].E, 3e-2)):
+        err = float((got.cpu() - T(zt[name])).abs().max())
+        assert err <= tol, (name, err)
+    # the temperature must actually be in there: the same quantities at temperature 1 differ from the golden by far more
+    cfg.diffusion.temperature_scaling_node = cfg.diffusion.temperature_scaling_edge = 1.0
+    _, _, probs1, preds1 = model.sample_one_batch(data=data, get_chains=True, noise_fn=lambda c, shp: counter_noise(shp, c))
+    assert float((preds1[0][1].E.cpu() - T(zt['pred9_E'])).abs().max()) > 0.1
+    gx, ge = final.X.cpu().numpy(), final.E.cpu().numpy()
+    ax, ae = (gx == zt['chain_X']).mean(), (ge == zt['chain_E']).mean()
+    print(f'temperature chain vs reference: nodes {ax:.4f}, edges {ae:.4f}')
+    assert ax >= 0.97 and ae >= 0.985, (ax, ae)
 
 
 def test_sampling_properties_at_max_atoms():

@@ -239,6 +239,50 @@ def test_single_step_logits_and_chain_config0():
     assert np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
 
 
+def test_temperature_chain_vs_reference():
+    """tests/golden/chain_temp_tiny.npz (make_golden_r3.py): the reference's sample_one_batch(get_chains=True) at
+    temperature_scaling_node = 0.7, temperature_scaling_edge = 1.4, log_every_t = 3 on configs[0]'s tiny model.  The oracle's chain
+    equals it bit for bit, and at every logged step so do the state, p(z_s | z_t) after apply_mask and the prediction turned into
+    probabilities the reference's way, softmax(temperature * log_softmax(logits)) without the supernode class (sampling.py:82,118-144)."""
+    z0, sd, true, fwd = _tiny_setup()
+    z = load('chain_temp_tiny')
+    tx, te = (float(v) for v in z['temps'])
+    tabs = O.absorbing_tables(10, KX, KE, 1, 27, 0, NM, EM)
+    nz = lambda c, shp: counter_noise(shp, c)
+    zX, zE = O.sample_chain(fwd, true, tabs, 10, 10, 'product_and_sn', 28, nz, temp=(tx, te))
+    assert int(z['noise_calls']) == 22
+    assert np.array_equal(zX.argmax(-1).numpy(), z['chain_X']) and np.array_equal(zE.argmax(-1).numpy(), z['chain_E'])
+    assert not np.array_equal(z['chain_E'], z0['chain_E'])          # the temperatures do change the chain (configs[0] at 1.0)
+    # the same loop step by step, with what the reference records at the logged steps
+    X0, E0, nm = true['X'], true['E'], true['node_mask']
+    B, n = nm.shape
+    mx, me = O.free_masks(X0, nm, true['atom_map_numbers'], 'product_and_sn', 28)
+    c = 0
+    zX, zE = O.sample_from_limit(tabs['x_limit'], tabs['e_limit'], nm, nz(c, (B * n, KX)).reshape(B, n, KX), nz(c + 1, (B * n * n, KE)).reshape(B, n, n, KE))
+    zX, zE = O.apply_mask(X0, E0, zX, zE, mx, me)
+    c += 2
+    logged = [int(s) for s in z['logged_steps']]
+    assert logged == [9, 6, 3, 0] and [int(t) for t in z['sample_steps']] == [10, 7, 4, 1, 0]
+    for t in range(10, 0, -1):
+        lX, lE = fwd(zX, zE, torch.full((B, 1), float(t)))
+        qX, qE = nz(c, (B * n, KX)).reshape(B, n, KX), nz(c + 1, (B * n * n, KE)).reshape(B, n, n, KE)
+        c += 2
+        pX, pE, nX, nE = O.reverse_step(lX, lE, zX, zE, nm, tabs, t, X0, E0, mx, me, qX, qE, tx, te)
+        s = t - 1
+        if s in logged:
+            cX, cE = O.collapse_dense(zX, zE, nm)
+            assert np.array_equal(np.asarray(cX), z[f'sample{t}_X']) and np.array_equal(np.asarray(cE), z[f'sample{t}_E'])
+            mpX, mpE = O.apply_mask(X0, E0, pX, pE, mx, me)
+            close(mpX, z[f'prob{s}_X'], 2e-6); close(mpE, z[f'prob{s}_E'], 2e-6)
+            p0X = torch.softmax(tx * torch.log_softmax(lX, -1), -1)
+            p0E = torch.softmax(te * torch.log_softmax(lE, -1), -1)
+            p0X[..., -1] = 0.
+            p0X = p0X / p0X.sum(-1, keepdim=True)
+            m0X, m0E = O.apply_mask(X0, E0, p0X, p0E, mx, me)
+            close(m0X, z[f'pred{s}_X'], 2e-6); close(m0E, z[f'pred{s}_E'], 2e-6)
+        zX, zE = nX, nE
+
+
 def oracle_training_loss(z, sd, true, kind, pos=None, requires_grad=True):
     """The three training objectives (diffusion_abstract.py:198-222) on the reference's recorded (t, z_t), differentiable in `sd`."""
     from diffalign_amd import synthetic as S
