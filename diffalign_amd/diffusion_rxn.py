@@ -127,6 +127,62 @@ class DiscreteDenoisingDiffusionRxn(DiscreteDenoisingDiffusion):
         return acc[0], acc[1], acc[2]                                   # elbos, loss_t, loss_0: (bs * n_samples,)
 
     @torch.no_grad()
+    def compare_true_and_gen_atoms(self, true_X, gen_X, n, device=None):
+        """diffusion_rxn.py:538-566: 1.0 for every sample whose multiset of atom classes equals the true reaction's (both (N, n)
+        class indices; compared after sorting each row)."""
+        dev = true_X.device
+        same = (true_X.sort(dim=-1)[0] == gen_X.to(dev).sort(dim=-1)[0]).sum(dim=-1)
+        return (same == n).float()
+
+    @torch.no_grad()
+    def score_one_batch(self, final_samples, true_data, bs, n_samples, n, device=None, to_rxn_smiles=None, noise_fn=None):
+        """diffusion_rxn.py:495-536 without the rdkit-bound validity scores: canonical strings of the generated and the true reactions
+        (`to_rxn_smiles(X, E, atom_map_numbers) -> ['r1.r2>>p', ...]`, the caller's chemistry: mol.get_cano_smiles_from_dense in the
+        reference; default: the object's `rxn_smiles_fn`), duplicates dropped per condition, the bound of every distinct sample
+        estimated on the device (estimate_elbo_with_repeats), samples ranked by it and by the count-weighted probability
+        (sort_by_elbo, reactions_sorted_with_weighted_prob), top-k accuracy and reciprocal rank against the true reaction
+        (calculate_top_k), and the share of distinct samples with the right atoms per condition (compare_true_and_gen_atoms).
+        final_samples / true_data: collapsed PlaceHolders (class indices) of bs * n_samples graphs, condition-major.
+        Returns (scores, elbo_sorted_rxns, weighted_prob_sorted_rxns) as the reference does."""
+        import torch.nn.functional as F
+        to_rxn_smiles = to_rxn_smiles or getattr(self, 'rxn_smiles_fn', None)
+        if to_rxn_smiles is None:
+            raise NotImplementedError('score_one_batch needs to_rxn_smiles (dense classes -> canonical reaction strings): rdkit is not part '
+                                      'of this repository')
+        gen_rxn = list(to_rxn_smiles(final_samples.X, final_samples.E, getattr(final_samples, 'atom_map_numbers', None)))
+        true_rxn = list(to_rxn_smiles(true_data.X, true_data.E, getattr(true_data, 'atom_map_numbers', None)))
+        unique_indices, counts, is_unique = graph.get_unique_indices_from_reaction_list(gen_rxn)
+        keep = torch.tensor(is_unique, device=final_samples.X.device)
+        final_u, true_u = final_samples.select_subset(keep).get_new_object(), true_data.select_subset(keep).get_new_object()
+        gen_u = [r for r, u in zip(gen_rxn, is_unique) if u]
+        # share of a condition's distinct samples that have the true reaction's atoms (:406, 421-431)
+        match = self.compare_true_and_gen_atoms(true_u.X, final_u.X, n).cpu()
+        ui = torch.tensor(unique_indices)
+        scores = {'matching_atoms': torch.stack([match[(ui >= i * n_samples) & (ui < (i + 1) * n_samples)].mean() for i in range(bs)])}
+        kx, ke = len(self.dataset_info.atom_decoder), len(self.dataset_info.bond_decoder)
+        elbos, loss_t, loss_0 = self.estimate_elbo_with_repeats(
+            final_u.get_new_object(X=F.one_hot(final_u.X.long(), kx).float(), E=F.one_hot(final_u.E.long(), ke).float()), noise_fn=noise_fn)
+        rcts, prods = graph.split_reactions_to_reactants_and_products(gen_u)
+        counts = list(counts)
+        elbos = elbos.clone()
+        for i, rct in enumerate(rcts):                 # dummy samples '[U]>>product' parse to empty reactants: never ranked (:459-463)
+            if all(a == '' for a in rct):
+                elbos[i] = float('inf'); counts[i] = 0
+        topks = list(getattr(self.cfg.test, 'topks', []) or [])
+        by_elbo = self.sort_by_elbo(elbos, loss_t, loss_0, rcts, prods, is_unique=is_unique, counts=counts, bs=bs, n_samples=n_samples, k=topks)
+        lam = self.cfg.test.sort_lambda_value
+        by_weight = reactions_sorted_with_weighted_prob(by_elbo, lam)
+        if topks:
+            t_rcts, t_prods = graph.split_reactions_to_reactants_and_products(true_rxn)
+            t_rcts, t_prods = t_rcts[::n_samples], t_prods[::n_samples]            # one entry per condition (:476-477)
+            topk, mrr = graph.calculate_top_k(self.cfg, by_elbo, t_rcts, t_prods)
+            topk_w, mrr_w = graph.calculate_top_k(self.cfg, by_weight, t_rcts, t_prods)
+            scores['mrr'], scores[f'mrr_weighted_{lam}'] = mrr, mrr_w
+            for j, k_ in enumerate(topks):
+                scores[f'top-{k_}'], scores[f'top-{k_}_weighted_{lam}'] = topk[:, j], topk_w[:, j]
+        return scores, by_elbo, by_weight
+
+    @torch.no_grad()
     def sort_by_elbo(self, elbos, loss_t, loss_0, rct_smiles, prod_smiles, is_unique, counts, bs, n_samples, k=[10]):
         """diffusion_rxn.py:643-699: per condition, the unique samples sorted by ascending bound, as
         {product: [{'rcts','prod','elbo','loss_t','loss_0','sample_idx','count'}, ...]}."""

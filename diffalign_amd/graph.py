@@ -199,3 +199,46 @@ def save_samples_to_file_without_weighted_prob(filename, condition_idx, gen_rxns
         for i, p in enumerate(gen_rxns):
             f.write(f'(cond {condition_idx + i}) {true_rxn_strs[i]}:\n')
             f.writelines([f'\t{(x["rxn"], [x["elbo"], x["loss_t"], x["loss_0"], x["count"]])}\n' for x in gen_rxns[p]])
+
+
+# ---- host-side list logic of the scoring driver (utils/graph.py:160-187, 738-770; pure Python on reaction strings) ----------------
+
+def get_unique_indices_from_reaction_list(gen_rxn_smiles):
+    """utils/graph.py:160-187.  Reactions 'r1.r2>>p' are equal when their sorted reactant sets and their product are; returns
+    (index of the first occurrence of every distinct reaction in increasing order, how often each occurs, per-sample flag
+    'is a first occurrence').  The reference gets the same through np.unique on the normalised strings."""
+    first, count = {}, {}
+    for i, rxn in enumerate(gen_rxn_smiles):
+        rct, prod = rxn.split('>>')[0], rxn.split('>>')[1]
+        key = '.'.join(sorted(rct.split('.'))) + '>>' + prod
+        if key not in first:
+            first[key] = i
+            count[key] = 0
+        count[key] += 1
+    keys = sorted(first, key=lambda k: first[k])
+    unique_indices = [first[k] for k in keys]
+    firsts = set(unique_indices)
+    return unique_indices, [count[k] for k in keys], [i in firsts for i in range(len(gen_rxn_smiles))]
+
+
+def split_reactions_to_reactants_and_products(reactions):
+    """utils/graph.py:767-770: ([reactant, ...] per reaction, [product] per reaction)."""
+    return [r.split('>>')[0].split('.') for r in reactions], [[r.split('>>')[1]] for r in reactions]
+
+
+def calculate_top_k(cfg, elbo_sorted_rxns, true_rcts, true_prods):
+    """utils/graph.py:738-765: per condition (the dict's insertion order) whether the true reaction -- as the SET of its reactant and
+    product strings -- is among the first k candidates for every k of cfg.test.topks, and the reciprocal rank of its first match
+    (0 when absent).  Returns (topk (bs, len(topks)) float, mrr (bs,) float)."""
+    ks = list(cfg.test.topks)
+    truth = [set(r) | set(p) for r, p in zip(true_rcts, true_prods)]
+    topk = torch.zeros(len(elbo_sorted_rxns), len(ks))
+    mrr = torch.zeros(len(elbo_sorted_rxns))
+    for i, rows in enumerate(elbo_sorted_rxns.values()):
+        cands = [set(row['rcts']) | set(row['prod']) for row in rows]
+        hit = next((rank for rank, c in enumerate(cands, 1) if c == truth[i]), None)
+        for j, k in enumerate(ks):
+            topk[i, j] = float(hit is not None and hit <= k)
+        if hit is not None:
+            mrr[i] = 1.0 / hit
+    return topk, mrr

@@ -8,6 +8,11 @@ container, third-party modules it lacks stubbed, torch.multinomial replaced by t
                         probabilities, softmax(temperature * log_softmax(logits)) with the supernode class dropped (:118-129).
                         Pins the temperature path, which every other fixture runs at 1.0.
 
+  scoring_lists.npz     the list logic of the scoring driver on synthetic canonical reaction strings (3 conditions x 5 samples with
+                        duplicates, permuted reactants and a dummy '>>product' sample): get_unique_indices_from_reaction_list,
+                        split_reactions_to_reactants_and_products (utils/graph.py:160-187, 767-770), then sort_by_elbo +
+                        reactions_sorted_with_weighted_prob on seeded scores and calculate_top_k (:738-765) of both rankings.
+
 Run:  CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" python tests/golden/make_golden_r3.py
 """
 import os
@@ -55,8 +60,45 @@ def gen_temperature_chain():
     print('logged steps', out['logged_steps'].tolist(), 'sample steps', out['sample_steps'].tolist(), 'noise calls', out['noise_calls'])
 
 
+from tests.golden.make_golden_r3_strings import scoring_strings   # noqa: E402
+
+
+def gen_scoring_lists():
+    import json
+    import numpy as np
+    from diffalign.diffusion.diffusion_rxn import DiscreteDenoisingDiffusionRxn as RefRxn
+    from diffalign.utils import graph as ref_graph
+    gen, true = scoring_strings()
+    bs, ns_ = 3, 5
+    unique_indices, counts, is_unique = ref_graph.get_unique_indices_from_reaction_list(gen)
+    gen_u = [r for r, u in zip(gen, is_unique) if u]
+    rcts, prods = ref_graph.split_reactions_to_reactants_and_products(gen_u)
+    g = torch.Generator().manual_seed(21)
+    elbos = torch.rand(len(gen_u), generator=g) * 40 + 5
+    loss_t = torch.rand(len(gen_u), generator=g) * 30
+    loss_0 = -torch.rand(len(gen_u), generator=g)
+    counts = [int(c) for c in counts]
+    for i, rct in enumerate(rcts):                       # diffusion_rxn.py:459-463
+        if len([a for a in rct if a == '']) == len(rct):
+            elbos[i] = float('inf'); counts[i] = 0
+    cfg = G.ns(test=G.ns(topks=[1, 2, 3], sort_lambda_value=0.3))
+    res = RefRxn.sort_by_elbo(None, elbos, loss_t, loss_0, rcts, prods, is_unique, counts, bs, ns_, k=cfg.test.topks)
+    ranked = ref_graph.reactions_sorted_with_weighted_prob(res, 0.3)
+    t_r, t_p = ref_graph.split_reactions_to_reactants_and_products(true)
+    t_r, t_p = t_r[::ns_], t_p[::ns_]
+    topk, mrr = ref_graph.calculate_top_k(cfg, res, t_r, t_p)
+    topk_w, mrr_w = ref_graph.calculate_top_k(cfg, ranked, t_r, t_p)
+    js = lambda o: np.frombuffer(json.dumps(o, sort_keys=True).encode(), dtype=np.uint8)
+    G.save('scoring_lists', unique_indices=torch.tensor([int(i) for i in unique_indices]), counts=torch.tensor(counts),
+           is_unique=torch.tensor([bool(u) for u in is_unique]), elbos=elbos, loss_t=loss_t, loss_0=loss_0, topk=topk, mrr=mrr,
+           topk_weighted=topk_w, mrr_weighted=mrr_w, split_json=js([rcts, prods]), sorted_json=js(res), ranked_json=js(ranked))
+    print('unique', [int(i) for i in unique_indices], 'counts', counts, 'topk', topk.tolist(), 'mrr', mrr.tolist())
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     G.check_race_equals_multinomial()
-    gen_temperature_chain()
+    which = sys.argv[1:] or ['temperature', 'scoring']
+    if 'temperature' in which: gen_temperature_chain()
+    if 'scoring' in which: gen_scoring_lists()
     print('done')

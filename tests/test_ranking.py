@@ -29,6 +29,38 @@ def test_sort_by_elbo_and_weighted_ranking_match_reference():
             assert abs(a['weighted_prob'] - b['weighted_prob']) <= 1e-12 and a['rcts'] == b['rcts'] and a['count'] == b['count']
 
 
+def test_scoring_list_logic_matches_reference():
+    """tests/golden/scoring_lists.npz (make_golden_r3.py): the reference's get_unique_indices_from_reaction_list,
+    split_reactions_to_reactants_and_products and calculate_top_k (utils/graph.py:160-187, 738-770) on 3 conditions x 5 synthetic
+    reaction strings with duplicates, permuted reactants and a dummy '>>product' sample, through sort_by_elbo and the weighted ranking."""
+    from types import SimpleNamespace as ns
+    from diffalign_amd import graph
+    from diffalign_amd.diffusion_rxn import DiscreteDenoisingDiffusionRxn as Rxn, reactions_sorted_with_weighted_prob
+    from tests.golden.make_golden_r3_strings import scoring_strings
+    z = load('scoring_lists')
+    gen, true = scoring_strings()
+    ui, counts, is_unique = graph.get_unique_indices_from_reaction_list(gen)
+    assert ui == [int(v) for v in z['unique_indices']] and is_unique == [bool(v) for v in z['is_unique']]
+    gen_u = [r for r, u in zip(gen, is_unique) if u]
+    rcts, prods = graph.split_reactions_to_reactants_and_products(gen_u)
+    assert [rcts, prods] == json.loads(bytes(z['split_json']).decode())
+    counts = list(counts)
+    elbos = torch.from_numpy(z['elbos']).clone()
+    for i, rct in enumerate(rcts):
+        if all(a == '' for a in rct):
+            assert torch.isinf(elbos[i]); counts[i] = 0
+    assert counts == [int(v) for v in z['counts']]
+    cfg = ns(test=ns(topks=[1, 2, 3], sort_lambda_value=0.3))
+    res = Rxn.sort_by_elbo(None, elbos, torch.from_numpy(z['loss_t']), torch.from_numpy(z['loss_0']), rcts, prods, is_unique, counts, 3, 5)
+    assert json.loads(json.dumps(res, sort_keys=True)) == json.loads(bytes(z['sorted_json']).decode())
+    ranked = reactions_sorted_with_weighted_prob(res, 0.3)
+    t_r, t_p = graph.split_reactions_to_reactants_and_products(true)
+    topk, mrr = graph.calculate_top_k(cfg, res, t_r[::5], t_p[::5])
+    topk_w, mrr_w = graph.calculate_top_k(cfg, ranked, t_r[::5], t_p[::5])
+    assert torch.equal(topk, torch.from_numpy(z['topk'])) and torch.equal(mrr, torch.from_numpy(z['mrr']))
+    assert torch.equal(topk_w, torch.from_numpy(z['topk_weighted'])) and torch.equal(mrr_w, torch.from_numpy(z['mrr_weighted']))
+
+
 def test_sparse_fields_and_text_formats(tmp_path):
     """SURVEY 8 f-4 (what can be built without torch_geometric / rdkit): the per-graph fields of PlaceHolder.pyg()
     (utils/placeholder.py:165-179, dense_to_sparse order and dtypes) and the samples_*.txt layout (utils/graph.py:786-800)."""
