@@ -147,7 +147,7 @@ def train_rooflines(B, n, dev, bf16, dx=256, de=64):
     out = []
     for name, fn, nbytes, what in (
             ('k_attn_bwd4 (+ k_attn_fold)', f_bwd, R * dx * eb * 5, 'E1, E2, dZ read, dE1, dE2 written once per pair-channel'),
-            ('k_wgrad_partial<64,256> (+ k_wgrad_fold)', f_wg, R * (de + dx) * eb, 'X and dY rows read once')):
+            (('k_wgrad_partial_bf16<64,256>' if bf16 else 'k_wgrad_partial<64,256>') + ' (+ k_wgrad_fold)', f_wg, R * (de + dx) * eb, 'X and dY rows read once')):
         ms = timed(fn)
         out.append({'kernel': name, 'bound': 'hbm', 'achieved': nbytes / ms / 1e6, 'peak': 8000.0, 'unit': 'GB/s', 'frac': nbytes / ms / 1e6 / 8000.0,
                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes, 'storage': 'bf16' if bf16 else 'f32', 'what': what, 'traffic': None})

@@ -10,7 +10,7 @@
 //   k_adamw                     AdamW with amsgrad, one fused pass over a flat parameter buffer (utils/setup.py:356)
 // Training batches are small (8-16 graphs, n <= 140: align_absorbing.yaml:49-88), so 256-wide per-pair tensors are materialised
 // here in fp32 (321 MB each at B = 16, n = 140), as the reference does; everything is HBM-bound streaming.
-#include "common.h"
+#include "mfma_util.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -602,6 +602,107 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const TX* __restrict__ X,
     }
   }
 }
+// Both operands in bf16 storage: the same split over rows on the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16: 16 rows per
+// instruction instead of 2, 1/16 of the matrix-pipe time of the fp32 form, which bounds that kernel at 75 us for 64 -> 256).  That
+// instruction wants 8 consecutive k per lane, and k is the ROW here while memory is contiguous along the features, so a 32-row x
+// 32-feature tile is first loaded the natural way -- lane (row, half) reads 16 contiguous bytes: the A-operand layout with k =
+// feature -- and turned by two identity MFMAs into accumulator layout (feature on the lane, 16 rows in registers); packed back to bf16
+// (exact: the values were bf16) its two register halves are the k-steps of the product.  dY and X tiles go through the same
+// transposition, so the row permutation it leaves (crow) is the same on both operands and the sum over rows does not see it.
+// Per 32 rows a wave issues 8 16-byte loads per lane (128 scalar loads in the fp32 form), 8 transposing and 8 multiplying MFMAs.
+template <int IN, int OUT, int WI, int WJ>
+__global__ void __launch_bounds__(256) k_wgrad_partial_bf16(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+                                                            float* __restrict__ bpart, long long R, int rows_per_wg) {
+  static_assert(WI * WJ == 4 && (IN / 32) % WI == 0 && (OUT / 32) % WJ == 0, "tiling");
+  constexpr int TI = IN / 32 / WI, TJ = OUT / 32 / WJ;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l32 = lane & 31, lh = lane >> 5;
+  const int wi = w / WJ, wj = w % WJ;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  f32x16 acc[TJ][TI];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) acc[tj][ti] = splat16(0.f);
+  float bs[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) bs[tj] = 0.f;
+  bf16x8 idn[2];                                                          // identity operand of k-step s: element j = (16 s + 8 h + j == n)
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) idn[s2][j] = (16 * s2 + 8 * lh + j == l32) ? (short)0x3F80 : (short)0;
+  const bf16_t* xp = X + (wi * TI) * 32 + 8 * lh;
+  const bf16_t* yp = dY + (wj * TJ) * 32 + 8 * lh;
+  uint4 ya[2][TJ][2], xa[2][TI][2];                                       // [buffer][tile][k-step of the transposition]
+  auto load = [&](int buf, long long r) {
+    const long long rr = min(r + l32, r1 - 1);                            // clamped, zeroed below
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) ya[buf][tj][s2] = *reinterpret_cast<const uint4*>(yp + rr * OUT + tj * 32 + 16 * s2);
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) xa[buf][ti][s2] = *reinterpret_cast<const uint4*>(xp + rr * IN + ti * 32 + 16 * s2);
+  };
+  auto compute = [&](int buf, long long r) {
+    const bool ok = r + l32 < r1;
+    const uint4 z4 = {0u, 0u, 0u, 0u};
+    bf16x8 yt[TJ][2], xt[TI][2];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      f32x16 t = splat16(0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) t = mfma32(frag_from_u4(ok ? ya[buf][tj][s2] : z4), idn[s2], t);   // rows past the slice: zero in dY
+      float sb = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sb += t[v];
+      bs[tj] += sb;
+      yt[tj][0] = pack_acc(t, 0); yt[tj][1] = pack_acc(t, 1);
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      f32x16 t = splat16(0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) t = mfma32(frag_from_u4(xa[buf][ti][s2]), idn[s2], t);
+      xt[ti][0] = pack_acc(t, 0); xt[ti][1] = pack_acc(t, 1);
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[tj][ti] = mfma32(yt[tj][q], xt[ti][q], acc[tj][ti]);
+  };
+  load(0, r0);
+  for (long long r = r0; r < r1; r += 64) {                               // two 32-row stages per trip, the loads of one under the MFMAs of the other
+    load(1, r + 32);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0, r);
+    __builtin_amdgcn_sched_barrier(0);
+    load(0, r + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 32 < r1) compute(1, r + 32);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* pw = part + (size_t)blockIdx.x * OUT * IN;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int o = (wj * TJ + tj) * 32 + crow(v, lh), i = (wi * TI + ti) * 32 + l32;
+        pw[(size_t)o * IN + i] = acc[tj][ti][v];
+      }
+  if (wi == 0) {                                                          // column sums of dY: lane = feature, both halves hold half of the rows
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float t = bs[tj] + __shfl_xor(bs[tj], 32);
+      if (lh == 0) bpart[(size_t)blockIdx.x * OUT + (wj * TJ + tj) * 32 + l32] = t;
+    }
+  }
+}
 // Fold of the G partial results (bias columns appended: partial g = nW weights then, in a second array, nB biases): workgroup = 32
 // outputs x 8 slice groups; a thread sums its group's partials in slice order, the 8 groups are then added in group order (LDS).
 __global__ void __launch_bounds__(256) k_wgrad_fold(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dW,
@@ -639,6 +740,29 @@ static void launch_wgrad(const TX* X, const TY* dY, float* dW, float* db, float*
   float* bpart = ws + (size_t)G * OUT * IN;
   k_wgrad_partial<IN, OUT, WI, WJ, TX, TY><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
   k_wgrad_fold<<<(IN * OUT + OUT + 31) / 32, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
+}
+
+template <int IN, int OUT, int WI, int WJ>
+static void launch_wgrad_bf16(const bf16_t* X, const bf16_t* dY, float* dW, float* db, float* ws, long long R, hipStream_t s) {
+  long long per = (R + WGRAD_MAX_SLICES - 1) / WGRAD_MAX_SLICES;
+  per = (per + 31) & ~31LL;                                               // rows are consumed 32 at a time
+  if (per < 64) per = 64;
+  const int G = (int)((R + per - 1) / per);
+  float* bpart = ws + (size_t)G * OUT * IN;
+  k_wgrad_partial_bf16<IN, OUT, WI, WJ><<<G, 256, 0, s>>>(X, dY, ws, bpart, R, (int)per);
+  k_wgrad_fold<<<(IN * OUT + OUT + 31) / 32, 256, 0, s>>>(ws, bpart, dW, db, G, IN * OUT, OUT);
+}
+static int wgrad_bf16(const bf16_t* X, const bf16_t* dY, float* dW, float* db, float* ws, long long R, int in_features, int out_features, hipStream_t s) {
+  switch (in_features * 1000 + out_features) {
+    case 64256: launch_wgrad_bf16<64, 256, 1, 4>(X, dY, dW, db, ws, R, s); break;
+    case 256064: launch_wgrad_bf16<256, 64, 4, 1>(X, dY, dW, db, ws, R, s); break;
+    case 64128: launch_wgrad_bf16<64, 128, 1, 4>(X, dY, dW, db, ws, R, s); break;
+    case 128064: launch_wgrad_bf16<128, 64, 4, 1>(X, dY, dW, db, ws, R, s); break;
+    case 64064: launch_wgrad_bf16<64, 64, 2, 2>(X, dY, dW, db, ws, R, s); break;
+    case 128128: launch_wgrad_bf16<128, 128, 2, 2>(X, dY, dW, db, ws, R, s); break;
+    default: da_set_error("da_linear_wgrad_mixed: %d -> %d features not built", in_features, out_features); return DA_ERR_UNSUPPORTED;
+  }
+  return DA_OK;
 }
 
 template <class TX, class TY>
@@ -906,7 +1030,8 @@ int da_linear_wgrad_mixed(const void* X, int x_bf16, const void* dY, int dy_bf16
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   int rc;
-  if (x_bf16 && dy_bf16) rc = wgrad_typed((const bf16_t*)X, (const bf16_t*)dY, dW, db, ws, R, in_features, out_features, s);
+  if (x_bf16 && dy_bf16 && (((uintptr_t)X | (uintptr_t)dY) & 15) != 0) { da_set_error("da_linear_wgrad_mixed: bf16 operands must be 16-byte aligned"); return DA_ERR_ARG; }
+  if (x_bf16 && dy_bf16) rc = wgrad_bf16((const bf16_t*)X, (const bf16_t*)dY, dW, db, ws, R, in_features, out_features, s);
   else if (x_bf16) rc = wgrad_typed((const bf16_t*)X, (const float*)dY, dW, db, ws, R, in_features, out_features, s);
   else if (dy_bf16) rc = wgrad_typed((const float*)X, (const bf16_t*)dY, dW, db, ws, R, in_features, out_features, s);
   else rc = wgrad_typed((const float*)X, (const float*)dY, dW, db, ws, R, in_features, out_features, s);

@@ -191,12 +191,13 @@ def test_pooled_statistics_forward_and_backward(shape):
 
 @pytest.mark.parametrize('xb,yb', [(True, True), (True, False), (False, True)])
 def test_wide_linear_weight_gradient_bf16_storage(xb, yb):
-    """da_linear_wgrad_mixed: bf16 operands are widened on load, products and the reduction are fp32 -> equal to the fp32 kernel on the
-    same (bf16-representable) values up to the order of the partial sums."""
+    """da_linear_wgrad_mixed: bf16 operands are widened on load (one of them bf16: fp32 MFMA) or fed to the bf16 MFMA through an exact
+    in-register transposition (both bf16); products and the reduction are fp32 -> equal to the fp32 kernel on the same
+    (bf16-representable) values up to the order of the partial sums.  Ragged row counts incl. fewer than one 32-row stage."""
     from diffalign_amd import _lib as L
     from diffalign_amd.autograd_ops import _workspace
     g = torch.Generator().manual_seed(9)
-    for fin, fout, R in ((64, 256, 5000), (256, 64, 777), (64, 128, 4097)):
+    for fin, fout, R in ((64, 256, 5000), (256, 64, 777), (64, 128, 4097), (128, 64, 31), (64, 64, 70001), (128, 128, 1)):
         x = torch.randn(R, fin, generator=g).to(torch.bfloat16).to(D); dy = torch.randn(R, fout, generator=g).to(torch.bfloat16).to(D)
         xa, ya = (x if xb else x.float()), (dy if yb else dy.float())
         dW = torch.empty(fout, fin, device=D); db = torch.empty(fout, device=D)
