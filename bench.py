@@ -179,7 +179,7 @@ def train_main(args, dev, dist, world, rank, emit=True, steps=None, warmup=None)
     if train_graph:                                    # the whole step replayed as one HIP graph (diffalign_amd/graphs.py)
         from diffalign_amd.graphs import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, data, group=group)
-        step_fn = lambda: gstep(data)
+        step_fn = lambda: gstep(data, next_data=data)     # the next batch is known (a prefetching loader): its encodings overlap this step
 
     def sync():
         if dist is not None:

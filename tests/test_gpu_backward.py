@@ -602,6 +602,24 @@ def test_device_step_adamw_and_graphed_training_step():
         model.eval(); l1 = probe()
     assert l1 < 0.8 * l0, (l0, l1)
     print('graphed training: probe loss', l0, '->', l1)
+    # positional encodings of the next batch computed beside the current replay (next_data=): the step that follows uses exactly them
+    model.train()
+    model.cfg.neuralnet.pos_encoding_type = 'laplacian_pos_enc'; model.cfg.neuralnet.num_lap_eig_vectors = 8
+    saved_fn, model.pos_encodings_fn = getattr(model, 'pos_encodings_fn', None), None
+    g2 = GraphedTrainStep(model, opt, data, warmup=1)
+    assert g2.pos is not None
+    other = data.get_new_object()
+    other.E = other.E.flip(0).contiguous(); other.X = other.X.flip(0).contiguous()
+    other.atom_map_numbers = other.atom_map_numbers.flip(0).contiguous(); other.mol_assignments = other.mol_assignments.flip(0).contiguous()
+    other.node_mask = other.node_mask.flip(0).contiguous()
+    g2(data, next_data=other)
+    assert g2._ahead[0] is other
+    l_a = float(g2(other))
+    assert '_ahead' not in g2.__dict__ and math.isfinite(l_a)
+    want = model.get_pos_encodings(other)
+    # (the Laplacian encodings carry random signs per call: compare up to the sign of each eigenvector column)
+    assert torch.allclose(g2.pos.abs(), want.abs(), atol=1e-5)
+    model.pos_encodings_fn = saved_fn
 
 
 def test_plain_graph_transformer_gradients_vs_oracle():
