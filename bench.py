@@ -229,7 +229,7 @@ def loop_object(args, model, step, z_t, data, masks, dev):
     saved = model.extra_features_fn
     model.extra_features_fn = None
     z_t.eig_cache = XF.EigCache.from_free_masks(masks[1], data.node_mask)
-    evs, orig = [], XF._eigen
+    evs, orig = [], XF._eigen_into
 
     def timed_eigen(*a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -247,7 +247,7 @@ def loop_object(args, model, step, z_t, data, masks, dev):
             torch.cuda.synchronize()
             out['ms_per_step'] = (time.perf_counter() - t0) / args.steps * 1e3
             out['graph_steps_per_s'] = z_t.X.shape[0] * 1e3 / out['ms_per_step']
-            XF._eigen = timed_eigen
+            XF._eigen_into = timed_eigen
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -257,7 +257,7 @@ def loop_object(args, model, step, z_t, data, masks, dev):
             out['eigensolver_ms'] = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
             out['eigensolver_share_of_step'] = out['eigensolver_ms'] / out['ms_per_step']
     finally:
-        XF._eigen = orig
+        XF._eigen_into = orig
         model.extra_features_fn = saved
         z_t.eig_cache = None
     out['what'] = ('ms_per_step: the headline step with --extra-features device (features + eigensolver inside the step, fixed block kept '

@@ -84,6 +84,7 @@ SIGNATURES = {
     'da_extra_eigen': 'i:ppqqppppppiip',
     'da_extra_eigen_solve': 'i:ppppppppiip',
     'da_extra_eigen_solve_cached': 'i:ppppppppiipppip',
+    'da_extra_eigen_solve_into': 'i:ppppipiiipppip',
     'da_extra_molecular': 'i:pppppfppiiip',
     'da_pos_product_index': 'i:pppppiip',
     'da_pos_sinusoidal': 'i:pppqip',

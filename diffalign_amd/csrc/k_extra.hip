@@ -26,8 +26,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- pass over the edge state: adjacency, Laplacian, valency sums ---------------------------------------------------
-// one wave per row (b,i).  A_ij = sum_{c>=1} E_ijc (extra_features.py:81), L = sym(D - A_m) on real nodes and 2n on the
-// padded diagonal (:105-109, :133-146), valency sums of extra_features_molecular.py:40-42 and :57-59.
+// one wave per row (b,i).  A_ij = sum_{c>=1} E_ijc (extra_features.py:81), the diagonal of L = sym(D - A_m) on real nodes and 2n
+// on padded ones (:105-109, :133-146), valency sums of extra_features_molecular.py:40-42 and :57-59.  The off-diagonal part
+// of L needs the transposed entry (the reference symmetrises L): k_extra_lap takes it from A through LDS tiles -- read here
+// from E it was one cache line per lane and pair, 200 us of this pass's 250 at B = 64, n = 300.
 __global__ void __launch_bounds__(256) k_extra_adj(const float* __restrict__ E, const uint8_t* __restrict__ node_mask,
                                                    const float* __restrict__ bond_orders, float* __restrict__ A,
                                                    double* __restrict__ L, float* __restrict__ val_weighted,
@@ -44,14 +46,13 @@ __global__ void __launch_bounds__(256) k_extra_adj(const float* __restrict__ E, 
   double deg = 0.0;
   for (int j = lane; j < n; j += 64) {
     const float* e = Er + (size_t)j * ke;
-    const float* et = E + (((size_t)b * n + j) * n + i) * ke;     // transposed entry (the reference symmetrises L)
-    float a = 0.f, at = 0.f, bw = -INFINITY, bp = -INFINITY;
+    float a = 0.f, bw = -INFINITY, bp = -INFINITY;
     int iw = 0, ip = 0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (c >= ke) break;
       const float v = e[c];
-      if (c >= 1) { a += v; at += et[c]; }
+      if (c >= 1) a += v;
       const float w = v * ord[c];
       if (w > bw) { bw = w; iw = c; }       // first maximum, as torch.argmax
       if (v > bp) { bp = v; ip = c; }
@@ -60,9 +61,7 @@ __global__ void __launch_bounds__(256) k_extra_adj(const float* __restrict__ E, 
     vw += (float)iw; vp += (float)ip;
     if (L) {
       const bool mj = node_mask[b * n + j] != 0;
-      const double am = (mi && mj) ? (double)a : 0.0, atm = (mi && mj) ? (double)at : 0.0;
-      deg += am;
-      if (j != i) L[(size_t)row * n + j] = -0.5 * (am + atm);   // the diagonal is written below (needs the whole row's degree)
+      deg += (mi && mj) ? (double)a : 0.0;
     }
   }
   vw = wave_sum(vw); vp = wave_sum(vp);
@@ -75,6 +74,37 @@ __global__ void __launch_bounds__(256) k_extra_adj(const float* __restrict__ E, 
       float aii = 0.f;
       for (int c = 1; c < ke; ++c) aii += e[c];
       L[(size_t)row * n + i] = mi ? deg - (double)aii : 2.0 * (double)n;   // (aii is 0 in every diffusion state: no self loops)
+    }
+  }
+}
+
+// off-diagonal entries of the Laplacian: L_ij = -(A_m[i][j] + A_m[j][i]) / 2 with A_m = A on pairs of real nodes, else 0.  One
+// workgroup per 32 x 32 tile; the mirrored tile of A comes through LDS so that both reads and the write are row-wise.
+__global__ void __launch_bounds__(256) k_extra_lap(const float* __restrict__ A, const uint8_t* __restrict__ node_mask,
+                                                   double* __restrict__ L, int n) {
+  __shared__ float s0[32][33], s1[32][33];
+  const int nt = (n + 31) / 32, b = blockIdx.y, it = blockIdx.x / nt, jt = blockIdx.x - it * nt;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const float* Ab = A + (size_t)b * n * n;
+  float v0[4], v1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                          // unconditional loads from clamped addresses; entries outside are never stored
+    const int rr = r0 + 8 * q;
+    v0[q] = Ab[(size_t)min(32 * it + rr, n - 1) * n + min(32 * jt + c, n - 1)];
+    v1[q] = Ab[(size_t)min(32 * jt + rr, n - 1) * n + min(32 * it + c, n - 1)];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { s0[r0 + 8 * q][c] = v0[q]; s1[r0 + 8 * q][c] = v1[q]; }
+  __syncthreads();
+  const int j = 32 * jt + c;
+  const bool mj = j < n && node_mask[b * n + min(j, n - 1)] != 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = r0 + 8 * q, i = 32 * it + rr;
+    if (i < n && j < n && i != j) {
+      const bool m = mj && node_mask[b * n + i] != 0;
+      const double am = m ? (double)s0[rr][c] : 0.0, atm = m ? (double)s1[c][rr] : 0.0;
+      L[((size_t)b * n + i) * n + j] = -0.5 * (am + atm);
     }
   }
 }
@@ -249,6 +279,10 @@ int da_extra_adjacency(const float* E, const uint8_t* node_mask, const float* bo
   DA_CHECK_ARG(B >= 0 && n >= 0 && ke >= 1 && ke <= 16, "da_extra_adjacency: need 1 <= ke <= 16 (got %d)", ke);
   if (B == 0 || n == 0) return DA_OK;
   k_extra_adj<<<cdiv(B * n, 4), 256, 0, (hipStream_t)stream>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke);
+  if (L) {
+    const int nt = (n + 31) / 32;
+    k_extra_lap<<<dim3(nt * nt, B), 256, 0, (hipStream_t)stream>>>(A, node_mask, L, n);
+  }
   DA_CHECK_LAUNCH("da_extra_adjacency");
   return DA_OK;
 }

@@ -358,11 +358,14 @@ __device__ __forceinline__ void back_transform(const double* __restrict__ A, int
   for (int q = 0; q < NQ; ++q) { const int j = lane + 64 * q; if (j < n && j >= own_lo && j < own_hi) y[j] = yq[q]; }
 }
 
+// Where the features go: n_comp[b * ld_nc], ev5[b * ld_ev + 0..4], nonlcc[(b n + i) * ld_nl], vec2[(b n + i) * ld_v2 + 0..1] --
+// dense tensors of their own (1, 5, 1, 2) or columns of the denoiser's input rows (da_extra_eigen_solve_into)
+struct EigOut { float *n_comp, *ev5, *nonlcc, *vec2; int ld_nc, ld_ev, ld_nl, ld_v2; };
+
 template <int EIG_THREADS>
 __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restrict__ Lmat, const uint8_t* __restrict__ node_mask,
-                                                                 const float* __restrict__ pad_noise, float* __restrict__ n_comp,
-                                                                 float* __restrict__ ev5, float* __restrict__ nonlcc,
-                                                                 float* __restrict__ vec2, double* __restrict__ evals_out, int n,
+                                                                 const float* __restrict__ pad_noise, const EigOut O,
+                                                                 double* __restrict__ evals_out, int n,
                                                                  const int* __restrict__ fixed_from, int* __restrict__ cache_state,
                                                                  double* __restrict__ cache, int mmax, int k_lds) {
   constexpr int EIG_NWV = EIG_THREADS / 64;
@@ -561,8 +564,8 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
     }
     __syncthreads();
   }
-  if (tid == 0) n_comp[b] = (float)ncomp;
-  if (tid < 5) ev5[(size_t)b * 5 + tid] = (ncomp + tid < n) ? (float)(S.lam[1 + tid] / nreal) : 2.f;   // :169-173
+  if (tid == 0) O.n_comp[(size_t)b * O.ld_nc] = (float)ncomp;
+  if (tid < 5) O.ev5[(size_t)b * O.ld_ev + tid] = (ncomp + tid < n) ? (float)(S.lam[1 + tid] / nreal) : 2.f;   // :169-173
 #ifndef EXP_EIG_STAMP
   if (evals_out && tid < 6) evals_out[(size_t)b * 6 + tid] = S.lam[tid];
 #endif
@@ -729,23 +732,21 @@ __global__ void __launch_bounds__(EIG_THREADS) k_extra_eig_solve(double* __restr
   const double mode = bv;
   for (int i = tid; i < n; i += EIG_THREADS) {
     const bool mi = m[i] != 0;
-    nonlcc[(size_t)b * n + i] = (mi && s_first[i] != mode) ? 1.f : 0.f;
+    O.nonlcc[((size_t)b * n + i) * O.ld_nl] = (mi && s_first[i] != mode) ? 1.f : 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int col = ncomp + k;
       double v = 0.0;
       if (col < n && mi && m[col]) v = S.y[(1 + k) * n + i];
-      vec2[((size_t)b * n + i) * 2 + k] = (float)v;
+      O.vec2[((size_t)b * n + i) * O.ld_v2 + k] = (float)v;
     }
   }
 }
 
 extern "C" {
 
-/* see include/diffalign_hip.h */
-int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
-                                float* vec2, double* evals6 /*may be NULL*/, int B, int n, const int* fixed_from, int* cache_state,
-                                double* cache, int mmax, void* stream) {
+static int eig_solve_launch(double* L, const uint8_t* node_mask, const float* pad_noise, const EigOut O, double* evals6, int B, int n,
+                            const int* fixed_from, int* cache_state, double* cache, int mmax, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 1 && n <= 1024, "da_extra_eigen_solve: n = %d outside 1..1024 (LDS work arrays)", n);
   DA_CHECK_ARG(cache == nullptr || (fixed_from != nullptr && cache_state != nullptr && mmax >= 1 && mmax <= n),
                "da_extra_eigen_solve_cached: cache given without fixed_from / cache_state, or mmax = %d outside 1..n", mmax);
@@ -771,21 +772,33 @@ int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float
   // a step of the reduction is a chain of barrier-separated phases over at most n entries: 8 waves serve n <= 512 with cheaper barriers
   static const int force_threads = [] { const char* e = getenv("DA_EIG_THREADS"); return e ? atoi(e) : 0; }();   // A/B hook
   if (force_threads == 256 && n <= 256)
-    k_extra_eig_solve<256><<<B, 256, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
-                                                                 fixed_from, cache_state, cache, mmax, k_lds);
+    k_extra_eig_solve<256><<<B, 256, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, O, evals6, n, fixed_from, cache_state, cache, mmax, k_lds);
   else if (n <= 512 && force_threads != 1024)
-    k_extra_eig_solve<512><<<B, 512, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
-                                                                 fixed_from, cache_state, cache, mmax, k_lds);
+    k_extra_eig_solve<512><<<B, 512, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, O, evals6, n, fixed_from, cache_state, cache, mmax, k_lds);
   else
-    k_extra_eig_solve<1024><<<B, 1024, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, n,
-                                                                   fixed_from, cache_state, cache, mmax, k_lds);
+    k_extra_eig_solve<1024><<<B, 1024, lds, (hipStream_t)stream>>>(L, node_mask, pad_noise, O, evals6, n, fixed_from, cache_state, cache, mmax, k_lds);
   DA_CHECK_LAUNCH("da_extra_eigen_solve");
   return DA_OK;
+}
+
+/* see include/diffalign_hip.h */
+int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
+                                float* vec2, double* evals6 /*may be NULL*/, int B, int n, const int* fixed_from, int* cache_state,
+                                double* cache, int mmax, void* stream) {
+  const EigOut O = {n_comp, ev5, nonlcc, vec2, 1, 5, 1, 2};
+  return eig_solve_launch(L, node_mask, pad_noise, O, evals6, B, n, fixed_from, cache_state, cache, mmax, stream);
 }
 
 int da_extra_eigen_solve(double* L, const uint8_t* node_mask, const float* pad_noise, float* n_comp, float* ev5, float* nonlcc,
                          float* vec2, double* evals6 /*may be NULL*/, int B, int n, void* stream) {
   return da_extra_eigen_solve_cached(L, node_mask, pad_noise, n_comp, ev5, nonlcc, vec2, evals6, B, n, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int da_extra_eigen_solve_into(double* L, const uint8_t* node_mask, const float* pad_noise, float* x_feat, int ldx, float* y_feat, int ldy,
+                              int B, int n, const int* fixed_from, int* cache_state, double* cache, int mmax, void* stream) {
+  DA_CHECK_ARG(x_feat != nullptr && y_feat != nullptr && ldx >= 3 && ldy >= 6, "da_extra_eigen_solve_into: need x_feat, y_feat, ldx >= 3 and ldy >= 6");
+  const EigOut O = {y_feat, y_feat + 1, x_feat, x_feat + 1, ldy, ldy, ldx, ldx};
+  return eig_solve_launch(L, node_mask, pad_noise, O, nullptr, B, n, fixed_from, cache_state, cache, mmax, stream);
 }
 
 }  // extern "C"

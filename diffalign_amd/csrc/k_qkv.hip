@@ -34,33 +34,42 @@ __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X
         af[s0 + u] = frag_from_u4(au);
       }
   }
-  // rows of this lane's accumulator registers: key/query row 32jt + crow(i,h); dead rows (j >= n) and masked nodes give 0
-  float rm[16];
+  // rows of this lane's accumulator registers: key/query row 32jt + crow(i,h); dead rows (j >= n) and masked nodes give 0.
+  // Kept as one bit per row: sixteen floats here were what pushed the kernel over 256 registers, and the reload of a spilled
+  // register waits with vmcnt(0), which drained the next tile's prefetched weights in front of every tile.
+  unsigned rmask = 0;
   {
     uint8_t mb[16];                                    // loaded unconditionally, as one batch (16 guarded loads were 16 round trips)
 #pragma unroll
     for (int i = 0; i < 16; ++i) mb[i] = mask[(size_t)b * n + min(32 * jt + crow(i, h), n - 1)];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rm[i] = (32 * jt + crow(i, h) < n && mb[i]) ? 1.f : 0.f;
+    for (int i = 0; i < 16; ++i) rmask |= ((32 * jt + crow(i, h) < n && mb[i]) ? 1u : 0u) << i;
   }
-  auto load_w = [&](uint4 (&wf)[KS], int t) {
-    const uint4* wp = W + ((size_t)min(t, 3 * NCB - 1) * KS) * 64 + lane;
+  const bool full = 32 * jt + 32 <= n;                 // wave-uniform: every row of the tile exists (no per-store branch)
+  // the tile's bias travels with its weights, issued first: a load issued behind the prefetch returns behind it
+  auto load_w = [&](uint4 (&wf)[KS], float& bv, int t) {
+    const int tc = min(t, 3 * NCB - 1);
+    bv = bias[32 * tc + r];
+    const uint4* wp = W + ((size_t)tc * KS) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < KS; ++s) wf[s] = wp[s * 64];
   };
-  auto tile = [&](const uint4 (&wf)[KS], int t) {
+  auto tile = [&](const uint4 (&wf)[KS], float bv, int t) {
     f32x16 acc = splat16(0.f);
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = mfma32(af[s], frag_from_u4(wf[s]), acc);
-    const float bv = bias[32 * t + r];
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = rm[i] * (acc[i] + bv);
+    for (int i = 0; i < 16; ++i) v[i] = ((rmask >> i) & 1u ? 1.f : 0.f) * (acc[i] + bv);
     if (t < NCB) {                                   // Q: fp32 rows
+      float* qp = Q + ((size_t)b * n + 32 * jt) * DX + 32 * t + r;
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int j = 32 * jt + crow(i, h);
-        if (j < n) Q[((size_t)b * n + j) * DX + 32 * t + r] = v[i];
+        for (int i = 0; i < 16; ++i) qp[(size_t)crow(i, h) * DX] = v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (32 * jt + crow(i, h) < n) qp[(size_t)crow(i, h) * DX] = v[i];
       }
     } else {                                         // K, V: fragment words
       const int kv = (t - NCB) / NCB, cb = (t - NCB) - kv * NCB;
@@ -72,14 +81,20 @@ __global__ void __launch_bounds__(256, 2) k_qkv_frag(const float* __restrict__ X
     }
   };
   uint4 wA[KS], wB[KS];
+  float bA, bB;
   constexpr int TPW = 3 * NCB / QKV_PARTS;             // column tiles per wave
+  static_assert(TPW % 2 == 0, "column tiles are walked in pairs");
   const int t0 = part * TPW, t1 = t0 + TPW;
-  load_w(wA, t0);
+  load_w(wA, bA, t0);
   for (int t = t0; t < t1; t += 2) {
-    load_w(wB, t + 1);
-    tile(wA, t);
-    load_w(wA, t + 2);
-    if (t + 1 < t1) tile(wB, t + 1);
+    load_w(wB, bB, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    tile(wA, bA, t);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(wA, bA, t + 2);                             // past the last pair: a clamped, unused fetch
+    __builtin_amdgcn_sched_barrier(0);
+    tile(wB, bB, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -24,6 +24,11 @@ struct XPostCfg {
 // but every one of them takes a whole SIMD's registers, and the y chain's 1,024-thread workgroups that run beside this kernel then find
 // no CU to start on (engine._layers_node_on_main): with 4 the step is 1 - 2.6 % shorter.
 constexpr int XP_WPB = XP_WPB_;
+#ifdef EXP_XP_NOW            // timing hook (tools/build_variant.sh): every weight fragment is fragment 0 -> the kernel without its weight stream
+#define XP_FR(i) 0
+#else
+#define XP_FR(i) (i)
+#endif
 template <int DX, int DFF>
 __global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict__ newX_in, const float* __restrict__ X,
                                                 const uint8_t* __restrict__ mask, const uint4* __restrict__ blob,
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict_
   for (int mt = 0; mt < C::MT; ++mt) {
     f32x16 acc = splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < C::KSX; ++s) acc = mfma32(frag_from_u4(fr[(C::FR_XO + mt * C::KSX + s) * 64]), inB[s], acc);
+    for (int s = 0; s < C::KSX; ++s) acc = mfma32(frag_from_u4(fr[XP_FR(C::FR_XO + mt * C::KSX + s) * 64]), inB[s], acc);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c = 32 * mt + 8 * g + 4 * h;
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict_
         hacc[4 * g + 0] = bv.x; hacc[4 * g + 1] = bv.y; hacc[4 * g + 2] = bv.z; hacc[4 * g + 3] = bv.w;
       }
 #pragma unroll
-      for (int s = 0; s < C::KSX; ++s) hacc = mfma32(frag_from_u4(fr[(C::FR_W1 + ht * C::KSX + s) * 64]), xb[s], hacc);
+      for (int s = 0; s < C::KSX; ++s) hacc = mfma32(frag_from_u4(fr[XP_FR(C::FR_W1 + ht * C::KSX + s) * 64]), xb[s], hacc);
       // relu on the packed bf16 words (as 16-bit integers negative floats are negative)
       hB[2 * ht + 0] = __builtin_elementwise_max(pack_acc(hacc, 0), (bf16x8)(short)0);
       hB[2 * ht + 1] = __builtin_elementwise_max(pack_acc(hacc, 1), (bf16x8)(short)0);
@@ -129,7 +134,7 @@ __global__ void __launch_bounds__(64 * XP_WPB) k_x_post(const float* __restrict_
       o[4 * g + 0] = bv.x; o[4 * g + 1] = bv.y; o[4 * g + 2] = bv.z; o[4 * g + 3] = bv.w;
     }
 #pragma unroll
-    for (int s = 0; s < C::KSF; ++s) o = mfma32(frag_from_u4(fr[(C::FR_W2 + mt * C::KSF + s) * 64]), hB[s], o);
+    for (int s = 0; s < C::KSF; ++s) o = mfma32(frag_from_u4(fr[XP_FR(C::FR_W2 + mt * C::KSF + s) * 64]), hB[s], o);
 #pragma unroll
     for (int i = 0; i < 16; ++i) { x1[mt][i] += o[i]; sum2 += x1[mt][i]; }
   }

@@ -121,6 +121,7 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         overrides the built-in calculators, e.g. to feed precomputed features."""
         if self.extra_features_fn is not None:
             X_extra, y_extra = self.extra_features_fn(noisy_data)
+            Xw, yw = torch.cat((noisy_data.X, X_extra), -1), torch.cat((noisy_data.y, y_extra), -1)
         else:
             from . import extra_features as XF
             if self._extra_calc is None:
@@ -129,12 +130,12 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
             # is kept along the chain); objects derived from it (get_new_object) do not carry it
             if pad_noise is None:
                 pad_noise = getattr(noisy_data, 'pad_noise', None)                # per chain (sample_one_batch)
-            X_extra, y_extra = XF.compute_extra_features(noisy_data.X, noisy_data.E, noisy_data.node_mask, *self._extra_calc,
-                                                         pad_noise=pad_noise, eig_cache=getattr(noisy_data, 'eig_cache', None))
+            # base=: the widened rows are assembled in place, nothing is left to concatenate behind the eigensolver
+            Xw, yw = XF.compute_extra_features(noisy_data.X, noisy_data.E, noisy_data.node_mask, *self._extra_calc, pad_noise=pad_noise,
+                                               eig_cache=getattr(noisy_data, 'eig_cache', None), base=(noisy_data.X, noisy_data.y))
         # a view of noisy_data with widened X and y: the reference's get_new_object clones every field (E: 161 MB at the
         # benchmark size, 60 us per step) for an object that only feeds the denoiser
-        return PlaceHolder(X=torch.cat((noisy_data.X, X_extra), -1), E=noisy_data.E, y=torch.cat((noisy_data.y, y_extra), -1),
-                           node_mask=noisy_data.node_mask, atom_map_numbers=noisy_data.atom_map_numbers,
+        return PlaceHolder(X=Xw, E=noisy_data.E, y=yw, node_mask=noisy_data.node_mask, atom_map_numbers=noisy_data.atom_map_numbers,
                            mol_assignments=noisy_data.mol_assignments)
 
     def reverse_step(self, z_t, t_array, pos_encodings=None, transition_model=None, temperature=(1.0, 1.0), noise=None, chain_seeds=None,

@@ -193,38 +193,72 @@ class ExtraMolecularFeatures(nn.Module):
         return cv, torch.zeros((*E.shape[:-1], 0), device=E.device, dtype=E.dtype), w
 
 
+def _eigen_into(Lap, nm_u8, pad_noise, Xf, x_col, yf, y_col, cache: Optional[EigCache]):
+    """_eigen with the six features written by the solver itself into columns x_col.. of Xf's rows (nonlcc, vec2) and y_col.. of
+    yf's rows (n_comp, ev5): nothing is left to do behind the solver (da_extra_eigen_solve_into).  The library path
+    (`DA_EXTRA_EIGH=torch`, n > 1024) copies."""
+    B, n, _ = Lap.shape
+    if EIGENSOLVER != 'hip' or n > 1024:
+        ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise, cache=cache)
+        Xf[..., x_col] = nonlcc; Xf[..., x_col + 1:x_col + 3] = vec2
+        yf[:, y_col] = ncomp; yf[:, y_col + 1:y_col + 6] = ev5
+        return
+    assert Xf.is_cuda and Xf.is_contiguous() and yf.is_contiguous() and Xf.dtype == torch.float32 and yf.dtype == torch.float32
+    use = cache is not None and cache.store is not None and EIG_CACHE
+    if use:
+        assert cache.n == n and cache.state.shape[0] == B and cache.state.device == Lap.device, 'EigCache belongs to another batch'
+    null = C.c_void_p(0)
+    L.check(L.lib().da_extra_eigen_solve_into(L.ptr(Lap, torch.float64), L.ptr(nm_u8), L.ptr(pad_noise.contiguous(), torch.float32),
+                                              C.c_void_p(Xf.data_ptr() + 4 * x_col), _i(Xf.shape[-1]),
+                                              C.c_void_p(yf.data_ptr() + 4 * y_col), _i(yf.shape[-1]), _i(B), _i(n),
+                                              L.ptr(cache.fixed_from, torch.int32) if use else null,
+                                              L.ptr(cache.state, torch.int32) if use else null,
+                                              L.ptr(cache.store, torch.float64) if use else null, _i(cache.mmax if use else 0), L.stream()),
+            'da_extra_eigen_solve_into')
+
+
 def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: ExtraMolecularFeatures,
-                           pad_noise: Optional[torch.Tensor] = None, eig_cache: Optional[EigCache] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           pad_noise: Optional[torch.Tensor] = None, eig_cache: Optional[EigCache] = None,
+                           base: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The two calculators of diffusion_abstract.py:350-372 with ONE pass over the edge state.
-    Returns (X_extra (B,n,8), y_extra (B,12)) in the reference's concatenation order (features_type 'all')."""
+    Returns (X_extra (B,n,8), y_extra (B,12)) in the reference's concatenation order (features_type 'all'), or, with
+    base = (X0, y0), the denoiser's widened inputs (cat(X0, X_extra), cat(y0, y_extra)) of :366-371.  The rows are assembled in
+    place: everything but the six eigen-features sits in its columns while the eigensolver still runs, and the solver writes
+    those itself -- behind it, on the step's critical path, nothing is left (seven small torch launches before)."""
     assert extra.features_type == 'all'
     dev = E.device
+    B, n = node_mask.shape
     E = E.contiguous().float()
     nm_u8 = L.as_u8(node_mask)
+    X0, y0 = base if base is not None else (None, None)
+    kx0, ky0 = (X0.shape[-1], y0.shape[-1]) if base is not None else (0, 0)
+    Xf = torch.empty(B, n, kx0 + 8, device=dev); yf = torch.empty(B, ky0 + 12, device=dev)
     A, Lap, vw, vp = _adjacency(E, nm_u8, molecular.consts(dev)[1], True)
-    # the eigensolver runs one workgroup per graph (64 of 256 CUs at the benchmark batch): the cycle counts (two batched GEMMs and a
-    # kernel) and the molecular features run beside it on the caller's stream
-    side = _eig_stream(dev)
-    if side is None:
-        ncomp, ev5, nonlcc, vec2 = _eigen(Lap, nm_u8, pad_noise, cache=eig_cache)
+    if pad_noise is None:
+        pad_noise = torch.randn(node_mask.shape, device=dev)
+
+    def rest():                     # cycle counts (two batched GEMMs and a kernel), molecular features, the copies of X0 / y0
         x_cycles, y_cycles = _cycles(A, nm_u8)
         cv, w = molecular.from_valency_sums(X, vw, vp)
+        if base is not None:
+            Xf[..., :kx0] = X0; yf[:, :ky0] = y0
+        Xf[..., kx0:kx0 + 3] = x_cycles; Xf[..., kx0 + 6:] = cv
+        yf[:, ky0] = node_mask.sum(dim=1).float() / extra.max_n_nodes
+        yf[:, ky0 + 1:ky0 + 5] = y_cycles; yf[:, ky0 + 11:] = w
+
+    # the eigensolver runs one workgroup per graph (64 of 256 CUs at the benchmark batch): everything else runs beside it on the
+    # caller's stream
+    side = _eig_stream(dev)
+    if side is None:
+        _eigen_into(Lap, nm_u8, pad_noise, Xf, kx0 + 3, yf, ky0 + 5, eig_cache)
+        rest()
     else:
         main = torch.cuda.current_stream()
-        if pad_noise is None:
-            pad_noise = torch.randn(node_mask.shape, device=dev)
         ready = main.record_event()
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            eig = _eigen(Lap, nm_u8, pad_noise, cache=eig_cache)
+            _eigen_into(Lap, nm_u8, pad_noise, Xf, kx0 + 3, yf, ky0 + 5, eig_cache)
             done = side.record_event()
-        x_cycles, y_cycles = _cycles(A, nm_u8)
-        cv, w = molecular.from_valency_sums(X, vw, vp)
-        main.wait_event(done)
-        for t in eig:
-            t.record_stream(main)                            # allocated on the side stream, read (and released) on the caller's
-        ncomp, ev5, nonlcc, vec2 = eig
-    n_frac = node_mask.sum(dim=1, keepdim=True).float() / extra.max_n_nodes
-    X_extra = torch.cat((x_cycles, nonlcc.unsqueeze(-1), vec2, cv), dim=-1)
-    y_extra = torch.hstack((n_frac, y_cycles, ncomp.unsqueeze(-1), ev5, w))
-    return X_extra, y_extra
+        rest()
+        main.wait_event(done)       # (Xf, yf, Lap, pad_noise: allocated on the caller's stream, which has now waited for their last use)
+    return Xf, yf

@@ -444,6 +444,13 @@ int da_extra_eigen_solve_cached(double* L, const uint8_t* node_mask, const float
                                 float* nonlcc, float* vec2, double* evals6, int B, int n, const int* fixed_from, int* cache_state,
                                 double* cache, int mmax, void* stream);
 
+/* da_extra_eigen_solve_cached writing straight into the denoiser's input rows (diffusion_abstract.py:350-372 concatenates the
+ * features behind X and y: extra_features.py:66-72 orders them [cycles(3), nonlcc, vec2(2)] per node and [n, cycles(4), n_comp,
+ * ev5(5)] per graph): x_feat[(b n + i) * ldx + 0..2] = nonlcc, vec2[0], vec2[1];  y_feat[b * ldy + 0..5] = n_comp, ev5[0..4].
+ * Same values as the dense form; ldx >= 3, ldy >= 6; cache == NULL: uncached. */
+int da_extra_eigen_solve_into(double* L, const uint8_t* node_mask, const float* pad_noise, float* x_feat, int ldx, float* y_feat,
+                              int ldy, int B, int n, const int* fixed_from, int* cache_state, double* cache, int mmax, void* stream);
+
 /* charge = argmax_c(X_c * valencies_c) - val_weighted, valency = val_plain, weight = sum_i atom_weights[argmax X_i] /
  * max_weight (extra_features_molecular.py:29-72; the argmax INDEX is used, as in the reference). */
 int da_extra_molecular(const float* X, const float* valencies, const float* atom_weights, const float* val_weighted,

@@ -285,3 +285,55 @@ def test_eigensolver_matches_round2_outputs():
           f'{flag_diff} of {flag_tot} nodes; eigenvector pairs: {vec_tot} graphs, {vec_skip} inside larger clusters (not comparable), '
           f'{vec_bad} off by more than 1e-4 up to sign / basis (largest difference {vmax:.3g})')
     assert flag_diff <= 0.005 * flag_tot and vec_bad == 0
+
+
+@pytest.mark.parametrize('n,B', [(300, 3), (45, 4), (1, 2)])
+def test_laplacian_tiles_and_in_place_assembly(n, B):
+    """(i) da_extra_adjacency's Laplacian -- diagonal by the row pass, off-diagonal entries by the tiled pass that takes the
+    transposed entry of A through LDS -- against the reference's formula (extra_features.py:105-109, :133-146) evaluated with
+    torch in fp64, on a NON-symmetric fp32 state (the transposed entry matters) with padded nodes; exact.  (ii) the widened
+    denoiser inputs assembled in place (`base=`: the eigensolver writes its six features into the rows itself) equal the
+    concatenation of the dense results bit for bit, with and without the fixed-block cache."""
+    from diffalign_amd import extra_features as XF, synthetic as S
+    g = torch.Generator().manual_seed(n)
+    ke = 5
+    E = torch.rand(B, n, n, ke, generator=g)
+    nm = torch.ones(B, n, dtype=torch.bool)
+    if n > 2:
+        nm[0, n - 2:] = False; nm[-1, n // 2:] = False
+    A, Lap, _, _ = XF._adjacency(E.to(D), nm.to(D).view(torch.uint8), torch.zeros(ke, device=D), True)
+    a = torch.zeros(B, n, n)
+    for c in range(1, ke):
+        a = a + E[..., c]                                       # the kernel's order of additions
+    assert torch.equal(A.cpu(), a)
+    m2 = (nm[:, :, None] & nm[:, None, :])
+    am = (a * m2).double()
+    deg = am.sum(-1)
+    eye = torch.eye(n, dtype=torch.bool)
+    want = torch.where(eye, torch.where(nm, deg - torch.diagonal(a, dim1=1, dim2=2).double(), torch.full_like(deg, 2.0 * n))[:, :, None].expand(B, n, n),
+                       -0.5 * (am + am.transpose(1, 2)))
+    got = Lap.cpu()
+    off = ~eye
+    assert torch.equal(got[:, off], want[:, off])
+    assert torch.allclose(got[:, eye], want[:, eye], rtol=1e-13, atol=0)     # the row sum's order differs from torch's
+    if n < 40:
+        return
+    info = extra_info(SimpleNamespace)
+    ef, mf = XF.ExtraFeatures('all', info), XF.ExtraMolecularFeatures(info)
+    true = S.make_reaction_batch(B, n, seed=5, P=142 if n == 300 else None, kx=len(ATOMS))
+    z = S.noised_state(true, 200, 500, len(ATOMS) - 2, seed=6)
+    X, Ez, nmz = z['X'].to(D), z['E'].to(D), z['node_mask'].to(D)
+    y0 = torch.rand(B, 1, generator=g).to(D)
+    pn = torch.randn(B, n, generator=g).to(D)
+    Xe, ye = XF.compute_extra_features(X, Ez, nmz, ef, mf, pad_noise=pn)
+    assert Xe.shape == (B, n, 8) and ye.shape == (B, 12)
+    Xw, yw = XF.compute_extra_features(X, Ez, nmz, ef, mf, pad_noise=pn, base=(X, y0))
+    assert torch.equal(Xw, torch.cat((X, Xe), -1)) and torch.equal(yw, torch.cat((y0, ye), -1))
+    from diffalign_amd import graph
+    from diffalign_amd.placeholder import PlaceHolder
+    data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
+    masks = graph.get_node_masks(data, list(ATOMS), ['none', 'SINGLE', 'DOUBLE', 'TRIPLE', 'mol', 'within', 'across'], 'product_and_sn', 'product_and_sn')
+    cache = XF.EigCache.from_free_masks(masks[1], data.node_mask)
+    for _ in range(2):
+        Xc, yc = XF.compute_extra_features(X, Ez, nmz, ef, mf, pad_noise=pn, eig_cache=cache, base=(X, y0))
+        assert torch.equal(Xc, Xw) and torch.equal(yc, yw)
