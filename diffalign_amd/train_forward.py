@@ -221,9 +221,10 @@ def aligned_product_features(X, E, atom_map_numbers, mol_assignments, kx, ke, al
 PRECISION = _os.environ.get('DA_TRAIN_PRECISION', 'fp32')
 
 
-def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None):
-    """Differentiable forward of the denoiser module `m`; returns (X logits, E logits, y) like the module's forward."""
-    bf16 = getattr(m, 'train_precision', None) or PRECISION
+def forward_train(m, X, E, y, node_mask, atom_map_numbers=None, pos_encodings=None, mol_assignments=None, precision=None):
+    """Differentiable forward of the denoiser module `m`; returns (X logits, E logits, y) like the module's forward.
+    `precision` overrides the module's / the process's training precision (the fp32 inference mode passes 'fp32')."""
+    bf16 = precision or getattr(m, 'train_precision', None) or PRECISION
     if bf16 not in ('fp32', 'bf16'):
         raise ValueError(f"train precision {bf16!r}: 'fp32' or 'bf16'")
     bf16 = bf16 == 'bf16'

@@ -53,13 +53,28 @@ class _DenoiserBase(nn.Module):
         self._plist = None
         return super()._apply(fn, *a, **k)
 
+    # 'bf16' (default): the fused inference path (engine.model_forward: bf16 MFMA operands, fp32 accumulation, edge activations
+    # stored bf16 between layers).  'fp32': inference through the training forward's kernels with every tensor and GEMM in fp32
+    # (train_forward.py under no_grad; eval() switches its dropout off) -- several times slower and memory-hungry, there to show a
+    # chain on the HIP path without bf16 near-tie flips (tests/test_gpu_sampling.py checks configs[0] against the reference
+    # draw for draw) and to separate rounding from logic when a checkpoint disagrees.
+    inference_precision = 'bf16'
+
     def _differentiable(self):
         """train() mode with autograd on: the fp32 training forward (train_forward.py) instead of the fused bf16 inference path."""
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
+    def _unfused(self):
+        if self.inference_precision not in ('bf16', 'fp32'):
+            raise ValueError(f"inference_precision {self.inference_precision!r}: 'bf16' or 'fp32'")
+        return self._differentiable() or self.improved or self.inference_precision == 'fp32'
+
+    def _unfused_precision(self):
+        return 'fp32' if self.inference_precision == 'fp32' and not self._differentiable() else None
+
     def supports_fused_step(self):
         """da_edge_out_sample (the reverse step's edge half inside the output kernel) is built for 7 edge classes."""
-        return self.out_dim_E == 7 and not self.improved
+        return self.out_dim_E == 7 and not self.improved and self.inference_precision == 'bf16'
 
     def _check(self, X):
         if not X.is_cuda:
@@ -74,9 +89,9 @@ class GraphTransformerWithY(_DenoiserBase):
 
     def forward(self, X, E, y, node_mask, step=None):
         self._check(X)
-        if self._differentiable() or self.improved:
+        if self._unfused():
             from .train_forward import forward_train
-            return forward_train(self, X, E, y, node_mask) + (node_mask,)
+            return forward_train(self, X, E, y, node_mask, precision=self._unfused_precision()) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, step=step)
         yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
@@ -107,9 +122,10 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
     def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments, step=None):
         assert atom_map_numbers is not None
         self._check(X)
-        if self._differentiable() or self.improved:
+        if self._unfused():
             from .train_forward import forward_train
-            return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments) + (node_mask,)
+            return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
+                                 precision=self._unfused_precision()) + (node_mask,)
         pm = self._pack(X.device)
         if self.input_alignment:                                         # :630-647
             from .train_forward import aligned_product_features

@@ -66,6 +66,37 @@ def test_chain_config0_against_reference_golden():
     assert torch.equal(out.E, out.E.transpose(1, 2)) and bool((out.X.sum(-1) == 1).all()) and bool((out.E.sum(-1) == 1).all())
 
 
+def test_chain_config0_fp32_inference_reproduces_the_reference_draw_for_draw():
+    """The same chain through the fp32 inference mode (`model.model.inference_precision = 'fp32'`: the training forward's kernels
+    under no_grad, every tensor and GEMM fp32, separate posterior / draw kernels): no bf16 near-tie flips, so the HIP path has to
+    reproduce the reference's 10-step chain of configs[0] exactly, and its teacher-forced logits to fp32 rounding."""
+    from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
+    from diffalign_amd.placeholder import PlaceHolder
+    from diffalign_amd import synthetic as S
+    z = load('chain_elbo_tiny')
+    model = DiscreteDenoisingDiffusion(make_cfg(tiny_dims()), make_info(), device=D).eval()
+    model.model.load_state_dict(weights_of(z))
+    model.model.inference_precision = 'fp32'
+    assert not model.model.supports_fused_step()
+    am = T(z['am'])
+    pos = S.shared_pos_encodings(dict(atom_map_numbers=am), 64, seed=73).to(D)
+    model.pos_encodings_fn = lambda zt: pos
+    data = PlaceHolder(X=F.one_hot(T(z['true_X']), KX).float().to(D), E=F.one_hot(T(z['true_E']), KE).float().to(D),
+                       y=torch.zeros(4, 1, device=D), node_mask=T(z['node_mask']).to(D), atom_map_numbers=am.to(D),
+                       mol_assignments=T(z['mol']).to(D))
+    zt = data.get_new_object(X=F.one_hot(T(z['step_zt_X']), KX).float().to(D), E=F.one_hot(T(z['step_zt_E']), KE).float().to(D),
+                             y=torch.full((4, 1), 6.0, device=D))
+    with torch.no_grad():
+        pred = model.forward(zt, pos_encodings=pos)
+    rel = lambda a, b: ((a.cpu().double() - b.double()).norm() / b.double().norm()).item()
+    rx, re_ = rel(pred.X, T(z['step_logit_X'])), rel(pred.E, T(z['step_logit_E']))
+    print(f'fp32 inference, teacher-forced logits vs reference: rel-L2 nodes {rx:.2e}, edges {re_:.2e}')
+    assert rx <= 1e-5 and re_ <= 1e-5, (rx, re_)
+    out = model.sample_one_batch(data=data, noise_fn=lambda c, shp: counter_noise(shp, c))
+    gx, ge = out.X.argmax(-1).cpu().numpy(), out.E.argmax(-1).cpu().numpy()
+    assert np.array_equal(gx, z['chain_X']) and np.array_equal(ge, z['chain_E']), ((gx == z['chain_X']).mean(), (ge == z['chain_E']).mean())
+
+
 def test_temperature_chain_and_recorded_chains_against_reference_golden():
     """tests/golden/chain_temp_tiny.npz: the reference's sample_one_batch(get_chains=True) at temperature_scaling_node = 0.7 /
     _edge = 1.4 with log_every_t = 3 (make_golden_r3.py).  The temperature enters the posterior of every step (da_posterior_sample's
@@ -104,6 +135,14 @@ def test_temperature_chain_and_recorded_chains_against_reference_golden():
     ax, ae = (gx == zt['chain_X']).mean(), (ge == zt['chain_E']).mean()
     print(f'temperature chain vs reference: nodes {ax:.4f}, edges {ae:.4f}')
     assert ax >= 0.97 and ae >= 0.985, (ax, ae)
+    # the fp32 inference mode: recorded probabilities to fp32 rounding and the chain draw for draw
+    cfg.diffusion.temperature_scaling_node, cfg.diffusion.temperature_scaling_edge = (float(v) for v in zt['temps'])
+    model.model.inference_precision = 'fp32'
+    final, samples, probs, preds = model.sample_one_batch(data=data, get_chains=True, noise_fn=lambda c, shp: counter_noise(shp, c))
+    for name, got in (('prob9_X', probs[0][1].X), ('prob9_E', probs[0][1].E), ('pred9_X', preds[0][1].X), ('pred9_E', preds[0][1].E)):
+        err = float((got.cpu() - T(zt[name])).abs().max())
+        assert err <= 2e-5, (name, err)
+    assert np.array_equal(final.X.cpu().numpy(), zt['chain_X']) and np.array_equal(final.E.cpu().numpy(), zt['chain_E'])
 
 
 def test_sampling_properties_at_max_atoms():
