@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd4(const float* __restrict__ Q, 
     st4(Z + off, f1 + f2 * y);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float mn = fmaxf(m[t], y[t]), sc = expf(m[t] - mn), p = expf(y[t] - mn);
+      const float mn = fmaxf(m[t], y[t]), sc = __expf(m[t] - mn), p = __expf(y[t] - mn);
       l[t] = l[t] * sc + p; a[t] = a[t] * sc + p * v[t]; m[t] = mn;
     }
   }
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd4(const float* __restrict__ Q, 
         const f32x4 y = qk * e1 + e2;
         f32x4 attn;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) attn[u] = expf(y[u] - m[t][u]);
+        for (int u = 0; u < 4; ++u) attn[u] = __expf(y[u] - m[t][u]);
         attn *= inv_l[t];
         const f32x4 dy = dz * f2 + attn * (g[t] * v - D[t]);
         d1 += dz; d2 += dz * y;
