@@ -55,7 +55,7 @@ SIGNATURES = {
     'da_kv_frag_bytes': 'q:iii',
     'da_x_post_blob_bytes': 'q:ii', 'da_x_in_blob_bytes': 'q:iii', 'da_x_in': 'i:pippppiiip',
     'da_linear': 'i:pipipppiiiiip',
-    'da_x_post': 'i:pppppiiip',
+    'da_x_post': 'i:pppppiiip', 'da_x_post16': 'i:pppppiiip', 'da_x_post16_blob_bytes': 'q:ii',
     'da_add_layernorm': 'i:pppppiip',
     'da_x_in_finish': 'i:pppiip',
     'da_edge_in': 'i:pipppiiiip',

@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import pack
 
-N_STAT_CHUNKS = 32
+N_STAT_CHUNKS = 32                    # most partial sums per graph of the separate Etoy statistics pass (stat_chunks)
 N_XSTAT_CHUNKS = 8
 # Etoy statistics of layers >= 1 from the edge kernel's tail (da_edge_layer_stats) instead of a separate pass.  A ticket of the tail is
 # one (graph, chunk of pairs): about 1,300 pairs per ticket is where the counter's round trip and the per-ticket fold stop showing
@@ -23,6 +23,22 @@ _STATS_TAIL_ENV = os.environ.get('DA_STATS_TAIL')
 STATS_TAIL = _STATS_TAIL_ENV != '0'
 STATS_TAIL_MIN_N = 0 if _STATS_TAIL_ENV == '1' else 112
 _TAIL_CHUNKS_ENV = os.environ.get('DA_TAIL_CHUNKS')
+
+
+# Node tail of a layer: below this many rows the 16-row-tile kernel (two waves per SIMD; twice the weight stream per row) is the
+# faster one: 21.5 against 28.2 us at 7,200 rows, 22.5 / 28.8 at 8,960, 40.3 / 32.5 at 19,200 (tools/bench_node_chain.py)
+XPOST16_MAX_ROWS = int(os.environ.get('DA_XPOST16_MAX_ROWS', '12000'))
+
+
+_STAT_CHUNKS_ENV = os.environ.get('DA_STAT_CHUNKS')
+
+
+def stat_chunks(n: int) -> int:
+    """Workgroups per graph of the separate Etoy statistics pass (da_edge_stats): about 64 KB of the bf16 hidden tensor each.  With the
+    32 that suit n >= 130 a workgroup at n = 72 streams 20 KB and spends its time in the fold of its partial sums."""
+    if _STAT_CHUNKS_ENV:
+        return int(_STAT_CHUNKS_ENV)
+    return max(1, min(N_STAT_CHUNKS, (n * n) // 512))
 
 
 def tail_chunks(n: int) -> int:
@@ -121,6 +137,8 @@ class PackedModel:
                 n2=(f32(g(p + '.normX2.weight')), f32(g(p + '.normX2.bias'))),
                 xpost=(pack.x_post_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev)
                        if self.fused_x else None),
+                xpost16=(pack.x_post16_blob({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, p).to(dev)
+                         if self.fused_x and lib.da_x_post16_blob_bytes(_i(self.dx), _i(self.dffx)) > 0 else None),
                 film=_PtrArray(film), yup=_PtrArray(yup)))
 
 
@@ -131,8 +149,8 @@ def _linear(A, lda, W, bias, rowmask, out, ldc, M, N, K, relu):
 
 
 def edge_stats(E_bf16, B, n, de, out=None):
-    st = out if out is not None else torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
-    L.check(L.lib().da_edge_stats(L.ptr(E_bf16), L.ptr(st), _i(B), _i(n), _i(de), _i(N_STAT_CHUNKS), L.stream()), 'da_edge_stats')
+    st = out if out is not None else torch.empty(B, stat_chunks(n), 4, de, dtype=torch.float32, device=E_bf16.device)
+    L.check(L.lib().da_edge_stats(L.ptr(E_bf16), L.ptr(st), _i(B), _i(n), _i(de), _i(st.shape[1]), L.stream()), 'da_edge_stats')
     return st
 
 
@@ -152,12 +170,13 @@ def layer_film(pm: PackedModel, lw: dict, y, B, out):
 def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de):
     """Statistics partials of the input stage's output: from the class counts da_edge_in_sym left in `scratch` for the graphs
     its table served (no pass over the hidden tensor), da_edge_stats for the others."""
-    st = torch.empty(B, N_STAT_CHUNKS, 4, de, dtype=torch.float32, device=E_bf16.device)
+    nch = stat_chunks(n)
+    st = torch.empty(B, nch, 4, de, dtype=torch.float32, device=E_bf16.device)
     lib = L.lib()
     if de_in <= 8:
-        L.check(lib.da_edge_stats_table(L.ptr(scratch), L.ptr(st), _i(B), _i(de_in), _i(de), _i(N_STAT_CHUNKS), L.stream()),
+        L.check(lib.da_edge_stats_table(L.ptr(scratch), L.ptr(st), _i(B), _i(de_in), _i(de), _i(nch), L.stream()),
                 'da_edge_stats_table')
-    L.check(lib.da_edge_stats_skip(L.ptr(E_bf16), L.ptr(st), L.ptr(scratch), _i(B), _i(n), _i(de), _i(N_STAT_CHUNKS), L.stream()),
+    L.check(lib.da_edge_stats_skip(L.ptr(E_bf16), L.ptr(st), L.ptr(scratch), _i(B), _i(n), _i(de), _i(nch), L.stream()),
             'da_edge_stats_skip')
     return st
 
@@ -215,7 +234,10 @@ def _x_post(pm: PackedModel, lw: dict, newX_in, X, nm_u8, B, n, out=None):
     """Node tail of a layer (layers.py:266-273, 340-351): x_out + mask, normX1, FFN X, normX2."""
     dev, dx, R, lib, S = X.device, pm.dx, B * n, L.lib(), L.stream()
     X2 = out if out is not None else torch.empty(B, n, dx, device=dev)
-    if lw['xpost'] is not None:
+    if lw['xpost16'] is not None and R <= XPOST16_MAX_ROWS:
+        L.check(lib.da_x_post16(L.ptr(newX_in), L.ptr(X), L.ptr(nm_u8), L.ptr(lw['xpost16']), L.ptr(X2), _i(R), _i(dx), _i(pm.dffx), S),
+                'da_x_post16')
+    elif lw['xpost'] is not None:
         L.check(lib.da_x_post(L.ptr(newX_in), L.ptr(X), L.ptr(nm_u8), L.ptr(lw['xpost']), L.ptr(X2), _i(R), _i(dx), _i(pm.dffx), S),
                 'da_x_post')
     else:
@@ -336,7 +358,7 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
         nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
         tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
         st = st0 if li == 0 else (tail if tail is not None else st_pass)
-        st_next = (torch.empty(B, N_STAT_CHUNKS, 4, pm.de, dtype=torch.float32, device=dev)
+        st_next = (torch.empty(B, stat_chunks(n), 4, pm.de, dtype=torch.float32, device=dev)
                    if nxt is not None and not use_stats_tail(n) else None)
         X_next = torch.empty(B, n, pm.dx, device=dev)
         y_next = torch.empty(B, pm.dy, device=dev)
@@ -439,6 +461,23 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             xin_done = side2.record_event()
             alignment()
             align_done = side2.record_event()
+    yh = torch.empty(B, pm.dy, device=dev)
+    film0 = film_buffers(pm, B, dev) if side is not None else None
+    y_done0 = None
+
+    def y_input_path():
+        L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
+                            _i(pm.dy_in), _i(pm.hy), _i(pm.dy), L.stream()), 'da_y_in')
+
+    if side is None:
+        y_input_path()
+    else:                                            # y input MLP and the first layer's FiLM vectors beside the edge input stage; enqueued
+                                                     # BEFORE that stage (behind it in program order the two kernels also ran behind it)
+        with torch.cuda.stream(side):
+            side.wait_event(in_ready)
+            y_input_path()
+            layer_film(pm, pm.layers[0], yh, B, film0)
+            y_done0 = side.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
     sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     # one-hot symmetric inputs (every diffusion state): the first layer takes its input rows from the input stage's table through a
@@ -452,22 +491,6 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     else:
         L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
                                    _i(pm.he), S), 'da_edge_in_sym')
-    yh = torch.empty(B, pm.dy, device=dev)
-    film0 = film_buffers(pm, B, dev) if side is not None else None
-    y_done0 = None
-
-    def y_input_path():
-        L.check(lib.da_y_in(L.ptr(y), L.ptr(pm.in_y[0]), L.ptr(pm.in_y[1]), L.ptr(pm.in_y[2]), L.ptr(pm.in_y[3]), L.ptr(yh), _i(B),
-                            _i(pm.dy_in), _i(pm.hy), _i(pm.dy), L.stream()), 'da_y_in')
-
-    if side is None:
-        y_input_path()
-    else:                                            # y input MLP and the first layer's FiLM vectors beside the edge input stage
-        with torch.cuda.stream(side):
-            side.wait_event(in_ready)
-            y_input_path()
-            layer_film(pm, pm.layers[0], yh, B, film0)
-            y_done0 = side.record_event()
     # ---- layers
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
     if xin_done is not None:

@@ -89,6 +89,34 @@ def x_post_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
     return _blob(frags, params)
 
 
+_R16 = (_L & 15)[:, None]
+_G16 = (_L >> 4)[:, None]
+_K16_NAT = 8 * _G16 + _J                           # + 32 s
+_K16_C = 16 * (_J >> 2) + 4 * _G16 + (_J & 3)      # + 32 s
+
+
+def _frag16(W: torch.Tensor, tile: int, s: int, corder: bool) -> torch.Tensor:
+    """Fragment of v_mfma_f32_16x16x32_bf16 (csrc/k_x_post.hip, 16-row kernel): lane (r = l & 15, g = l >> 4), element e holds
+    W[16 tile + r][k], k = 32 s + 8 g + e (natural) or 32 s + 16 (e >> 2) + 4 g + (e & 3) (two accumulator tiles packed)."""
+    return W[16 * tile + _R16, (_K16_C if corder else _K16_NAT) + 32 * s]
+
+
+def x_post16_blob(sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    """Blob for da_x_post16; p = 'tf_layers.{l}' key prefix.  Layout = XPost16Cfg in csrc/k_x_post.hip: the output tiles of the three
+    GEMMs numbered through, dx / 32 fragments each."""
+    g = lambda k: sd[p + k].detach().float().cpu()
+    Wxo, W1, W2 = g('.self_attn.x_out.weight'), g('.linX1.weight'), g('.linX2.weight')
+    dx, dff = Wxo.shape[0], W1.shape[0]
+    assert dx == dff and dx % 32 == 0
+    ks = dx // 32
+    frags = [_frag16(Wxo, t, s, False) for t in range(dx // 16) for s in range(ks)]
+    frags += [_frag16(W1, t, s, True) for t in range(dx // 16) for s in range(ks)]
+    frags += [_frag16(W2, t, s, True) for t in range(dx // 16) for s in range(ks)]
+    params = [g('.self_attn.x_out.bias'), g('.normX1.weight'), g('.normX1.bias'), g('.linX1.bias'), g('.linX2.bias'),
+              g('.normX2.weight'), g('.normX2.bias')]
+    return _blob(frags, params)
+
+
 def x_in_blob(sd, prefix='') -> torch.Tensor:
     """Blob for da_x_in (mlp_in_X).  Layout = XInCfg in csrc/k_x_in.hip: W0 fragments [hidden/32][ceil(dx_in/16)] in natural k order
     (K zero padded), W1 fragments [dx/32][hidden/16] in C order, then b0, b1."""

@@ -249,6 +249,11 @@ int da_linear(const float* A, int lda, const void* W_bf16, int Kpad, const float
  * blob = diffalign_amd/pack.py x_post_blob (XPostCfg layout).  Built: (dx, dim_ffX) = (256,256), (64,64). */
 int da_x_post(const float* newX_in, const float* X, const uint8_t* node_mask, const void* blob, float* X_out, int rows, int dx,
               int dffx, void* stream);
+/* The same stage on 16-row tiles (v_mfma_f32_16x16x32_bf16, two waves per SIMD): blob = pack.py x_post16_blob (XPost16Cfg layout,
+ * da_x_post16_blob_bytes; -1: dims not built).  Same arithmetic, sums grouped by the tile shape. */
+long long da_x_post16_blob_bytes(int dx, int dffx);
+int da_x_post16(const float* newX_in, const float* X, const uint8_t* node_mask, const void* blob, float* X_out, int rows, int dx,
+                int dffx, void* stream);
 
 /* Node input stage, fused: X_h = encode_no_element(relu(mlp_in_X.2(relu(mlp_in_X.0(X)))) * mask) + pos_encodings
  * (transformer_model_with_y.py:584-585, 661, 666).  X (rows, dx_in) fp32 row-major with dx_in <= 96, pos (rows, dx) or NULL,

@@ -46,6 +46,12 @@ x1 = F.layer_norm(X + nx, (dx,), w['normX1.weight'], w['normX1.bias'])
 ref = F.layer_norm(x1 + F.linear(F.linear(x1, w['linX1.weight'], w['linX1.bias']).relu(), w['linX2.weight'], w['linX2.bias']), (dx,),
                    w['normX2.weight'], w['normX2.bias'])
 print(f'da_x_post   B={B} n={n} rows={R}: {us:6.1f} us   rel err {((out - ref).norm() / ref.norm()).item():.2e}')
+blob16 = pack.x_post16_blob(sd, p).to(D)
+assert blob16.numel() == lib.da_x_post16_blob_bytes(dx, dff)
+out16 = torch.empty(R, dx, device=D)
+call = lambda: L.check(lib.da_x_post16(L.ptr(newX_in), L.ptr(X), L.ptr(mask), L.ptr(blob16), L.ptr(out16), R, dx, dff, S), 'da_x_post16')
+us = timed(call)
+print(f'da_x_post16 B={B} n={n} rows={R}: {us:6.1f} us   rel err {((out16 - ref).norm() / ref.norm()).item():.2e}   vs 32-row kernel {((out16 - out).norm() / ref.norm()).item():.2e}')
 
 Wq = torch.cat([rnd(dx, dx) * 0.06 for _ in range(3)])
 bq = (rnd(3 * dx) * 0.1).to(D)
