@@ -30,39 +30,53 @@ __device__ __forceinline__ double wave_sum(double v) {
 // on padded ones (:105-109, :133-146), valency sums of extra_features_molecular.py:40-42 and :57-59.  The off-diagonal part
 // of L needs the transposed entry (the reference symmetrises L): k_extra_lap takes it from A through LDS tiles -- read here
 // from E it was one cache line per lane and pair, 200 us of this pass's 250 at B = 64, n = 300.
+// KE > 0: the class count as a compile-time constant (every load of a pair issued up front, two pairs per lane in flight: with
+// the run-time bound each class sat behind its own `c < ke` branch and was its own round trip); KE = 0: any ke <= 16.
+template <int KE>
 __global__ void __launch_bounds__(256) k_extra_adj(const float* __restrict__ E, const uint8_t* __restrict__ node_mask,
                                                    const float* __restrict__ bond_orders, float* __restrict__ A,
                                                    double* __restrict__ L, float* __restrict__ val_weighted,
-                                                   float* __restrict__ val_plain, int B, int n, int ke) {
+                                                   float* __restrict__ val_plain, int B, int n, int ke_rt) {
+  constexpr int KMAX = KE > 0 ? KE : 16;
+  const int ke = KE > 0 ? KE : ke_rt;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B * n) return;
   const int b = row / n, i = row - b * n;
   const bool mi = node_mask[row] != 0;
-  float ord[16];
+  float ord[KMAX];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) ord[c] = c < ke ? bond_orders[c] : 0.f;
+  for (int c = 0; c < KMAX; ++c) ord[c] = bond_orders[min(c, ke - 1)];
   const float* Er = E + (size_t)row * n * ke;
   float vw = 0.f, vp = 0.f;
   double deg = 0.0;
-  for (int j = lane; j < n; j += 64) {
-    const float* e = Er + (size_t)j * ke;
+  auto pair = [&](int j, const float (&v)[KMAX], uint8_t mjb) {      // v: the pair's classes (entries past ke unused)
     float a = 0.f, bw = -INFINITY, bp = -INFINITY;
     int iw = 0, ip = 0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      if (c >= ke) break;
-      const float v = e[c];
-      if (c >= 1) a += v;
-      const float w = v * ord[c];
-      if (w > bw) { bw = w; iw = c; }       // first maximum, as torch.argmax
-      if (v > bp) { bp = v; ip = c; }
+    for (int c = 0; c < KMAX; ++c) {
+      if (c < ke) {
+        if (c >= 1) a += v[c];
+        const float w = v[c] * ord[c];
+        if (w > bw) { bw = w; iw = c; }       // first maximum, as torch.argmax
+        if (v[c] > bp) { bp = v[c]; ip = c; }
+      }
     }
     A[(size_t)row * n + j] = a;
     vw += (float)iw; vp += (float)ip;
-    if (L) {
-      const bool mj = node_mask[b * n + j] != 0;
-      deg += (mi && mj) ? (double)a : 0.0;
-    }
+    deg += (mi && mjb != 0) ? (double)a : 0.0;
+  };
+  auto load = [&](int j, float (&v)[KMAX], uint8_t& mjb) {            // unconditional, from clamped addresses
+    const float* e = Er + (size_t)min(j, n - 1) * ke;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) v[c] = e[KE > 0 ? c : min(c, ke - 1)];
+    mjb = node_mask[b * n + min(j, n - 1)];
+  };
+  for (int j = lane; j < n; j += 128) {
+    float v0[KMAX], v1[KMAX];
+    uint8_t m0, m1;
+    load(j, v0, m0); load(j + 64, v1, m1);
+    pair(j, v0, m0);
+    if (j + 64 < n) pair(j + 64, v1, m1);
   }
   vw = wave_sum(vw); vp = wave_sum(vp);
   if (lane == 0) { val_weighted[row] = vw; val_plain[row] = vp; }
@@ -278,7 +292,14 @@ int da_extra_adjacency(const float* E, const uint8_t* node_mask, const float* bo
                        float* val_weighted, float* val_plain, int B, int n, int ke, void* stream) {
   DA_CHECK_ARG(B >= 0 && n >= 0 && ke >= 1 && ke <= 16, "da_extra_adjacency: need 1 <= ke <= 16 (got %d)", ke);
   if (B == 0 || n == 0) return DA_OK;
-  k_extra_adj<<<cdiv(B * n, 4), 256, 0, (hipStream_t)stream>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke);
+  const dim3 grid(cdiv(B * n, 4));
+  hipStream_t s = (hipStream_t)stream;
+  switch (ke) {
+    case 5: k_extra_adj<5><<<grid, 256, 0, s>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke); break;
+    case 7: k_extra_adj<7><<<grid, 256, 0, s>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke); break;
+    case 4: k_extra_adj<4><<<grid, 256, 0, s>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke); break;
+    default: k_extra_adj<0><<<grid, 256, 0, s>>>(E, node_mask, bond_orders, A, L, val_weighted, val_plain, B, n, ke); break;
+  }
   if (L) {
     const int nt = (n + 31) / 32;
     k_extra_lap<<<dim3(nt * nt, B), 256, 0, (hipStream_t)stream>>>(A, node_mask, L, n);
