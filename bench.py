@@ -395,7 +395,7 @@ def main():
         cache = getattr(z_t, 'eig_cache', None)
         gc.T_eval = T_eval
         pad = torch.randn(B, n, device=dev)
-        gc.load(data, masks, pos, None, None, seeds, z_t, cache, pad)
+        gc.load(data, masks, pos, None, None, seeds, z_t, cache, pad, t_start=50)
 
         def step():
             t = state['t']

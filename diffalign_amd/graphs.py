@@ -148,7 +148,9 @@ class GraphedChain:
         self.fix_nodes, self.fix_edges = cl(fix_nodes), cl(fix_edges)
         self.seeds = torch.zeros(B, dtype=torch.int64, device=dev)
         self.pad_noise = torch.zeros(B, n, device=dev)
-        self.z = self.data.get_new_object(y=torch.zeros(B, 1, device=dev))
+        # the chain's state alternates between two holders: step t reads zs[t & 1] and the reverse step writes zs[(t - 1) & 1] directly
+        # (two copies of the state per step before: two launches and two kernel boundaries of the 30 a step of a small batch has)
+        self.zs = [self.data.get_new_object(y=torch.zeros(B, 1, device=dev)) for _ in range(2)]
         step = model.T // self.T_eval
         self.all_t = torch.arange(self.T_eval + 1, device=dev)[:, None, None].expand(-1, B, 1).contiguous()
         self.all_y = self.all_t.float() * step
@@ -162,8 +164,9 @@ class GraphedChain:
         self.pool = torch.cuda.graph_pool_handle()
         self.warm = False
 
-    def load(self, data, masks, pos, fix_nodes, fix_edges, seeds, z_start, eig_cache, pad_noise):
-        """A new chain of this shape: its inputs go into the static buffers, the eigensolver's cache starts empty."""
+    def load(self, data, masks, pos, fix_nodes, fix_edges, seeds, z_start, eig_cache, pad_noise, t_start=None):
+        """A new chain of this shape: its inputs go into the static buffers, the eigensolver's cache starts empty.
+        `t_start`: the step the chain starts at (default T_eval): the start state goes into that step's input holder."""
         for name in ('X', 'E', 'y', 'node_mask', 'atom_map_numbers', 'mol_assignments'):
             dst, src = getattr(self.data, name), getattr(data, name)
             if dst is not None:
@@ -178,10 +181,12 @@ class GraphedChain:
         self.seeds.copy_(seeds)
         if pad_noise is not None:                            # drawn per chain only when the extra features' eigensolver runs
             self.pad_noise.copy_(pad_noise)
-        self.z.X.copy_(z_start.X); self.z.E.copy_(z_start.E)
-        for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
-            if getattr(self.z, name) is not None:
-                getattr(self.z, name).copy_(getattr(data, name))
+        z0 = self.zs[(self.T_eval if t_start is None else int(t_start)) & 1]
+        z0.X.copy_(z_start.X); z0.E.copy_(z_start.E)
+        for z in self.zs:
+            for name in ('node_mask', 'atom_map_numbers', 'mol_assignments'):
+                if getattr(z, name) is not None:
+                    getattr(z, name).copy_(getattr(data, name))
         if self.eig is not None:
             self.eig.fixed_from.copy_(eig_cache.fixed_from)
             self.eig.state.zero_()
@@ -193,25 +198,24 @@ class GraphedChain:
 
     def _body(self, t):
         from . import graph
-        m, z = self.model, self.z
+        m, z, zo = self.model, self.zs[t & 1], self.zs[(t - 1) & 1]
         z.eig_cache, z.pad_noise = self.eig, (self.pad_noise if self.eig is not None else None)
         z.y = self.all_y[t]
-        zsX, zsE, _ = m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
-                                     orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
-                                     call=self.first_call + (self.T_eval - t), tables=self._tables(t))
-        z.X.copy_(zsX); z.E.copy_(zsE)
-        graph.apply_inpainting(z, self.data, self.fix_nodes, self.fix_edges)
+        m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
+                       orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
+                       call=self.first_call + (self.T_eval - t), tables=self._tables(t), out=(zo.X, zo.E))
+        graph.apply_inpainting(zo, self.data, self.fix_nodes, self.fix_edges)
         if not m.cfg.diffusion.diffuse_edges:
-            z.E.copy_(self.data.E)
+            zo.E.copy_(self.data.E)
         if not m.cfg.diffusion.diffuse_nodes:
-            z.X.copy_(self.data.X)
+            zo.X.copy_(self.data.X)
 
     def run(self):
-        """All T_eval steps on the loaded chain; returns the static state holder (clone what must outlive the next chain)."""
+        """All T_eval steps on the loaded chain; returns the static state holder the last step wrote (clone what must outlive the next chain)."""
         return self.run_steps(self.T_eval, 1)
 
     def run_steps(self, t_from: int, t_to: int):
-        """Steps t_from, t_from - 1, ..., t_to on the loaded chain."""
+        """Steps t_from, t_from - 1, ..., t_to on the loaded chain (whose state sits in the input holder of step t_from)."""
         with torch.no_grad():
             for t in range(t_from, t_to - 1, -1):
                 g = self.graphs.get(t)
@@ -219,19 +223,18 @@ class GraphedChain:
                     if not self.warm:
                         # one eager step on a side stream first (lazy set-up that must not happen under capture: weight packing,
                         # function attributes, allocator pools); the state it changes is put back
-                        keep = (self.z.X.clone(), self.z.E.clone(), None if self.eig is None else self.eig.state.clone())
+                        keep = None if self.eig is None else self.eig.state.clone()     # (the step's input holder is only read)
                         s = torch.cuda.Stream()
                         s.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(s):
                             self._body(t)
                         torch.cuda.current_stream().wait_stream(s)
-                        self.z.X.copy_(keep[0]); self.z.E.copy_(keep[1])
                         if self.eig is not None:
-                            self.eig.state.copy_(keep[2])
+                            self.eig.state.copy_(keep)
                         self.warm = True
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=self.pool):
                         self._body(t)
                     self.graphs[t] = g
                 g.replay()
-        return self.z
+        return self.zs[(t_to - 1) & 1]
