@@ -201,15 +201,26 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
   // Tile loads: all of a thread's (up to 8) 16-byte pieces are requested before the first is used, from clamped addresses; with one
   // guarded load per trip a tile cost seven dependent HBM round trips, and its mirror seven more (103 -> 60 us at B = 64, n = 300).
   constexpr int UN_T = 8;                              // 32 rows x 8 de_in float4 / 256 threads, de_in <= 8
+  const bool batched = vec && 32 * W4 <= UN_T * 256;   // (vec: n de_in % 4 == 0, hence vw % 4 == 0 and every row start is 16-byte aligned)
+  float4 qm[UN_T];                                     // the mirrored tile (jt, it), requested together with tile (it, jt): one HBM latency, not two
   {
     const int vw = min(32, n - jt * 32) * de_in;       // valid floats of a tile row
-    if (vec && 32 * W4 <= UN_T * 256) {                // (vec: n de_in % 4 == 0, hence vw % 4 == 0 and every row start is 16-byte aligned)
+    if (batched) {
       float4 v[UN_T];
 #pragma unroll
       for (int u = 0; u < UN_T; ++u) {
         const int t = min((int)threadIdx.x + u * 256, 32 * W4 - 1);
         const int ri = t / W4, o = (t - ri * W4) * 4;
         v[u] = *reinterpret_cast<const float4*>(base + ((size_t)min(it * 32 + ri, n - 1) * n + jt * 32) * de_in + max(min(o, vw - 4), 0));
+      }
+      {
+        const int vwm = min(32, n - it * 32) * de_in;
+#pragma unroll
+        for (int u = 0; u < UN_T; ++u) {
+          const int t = min((int)threadIdx.x + u * 256, 32 * W4 - 1);
+          const int rj = t / W4, o = (t - rj * W4) * 4;
+          qm[u] = *reinterpret_cast<const float4*>(base + ((size_t)min(jt * 32 + rj, n - 1) * n + it * 32) * de_in + max(min(o, vwm - 4), 0));
+        }
       }
 #pragma unroll
       for (int u = 0; u < UN_T; ++u) {
@@ -242,25 +253,22 @@ __global__ void __launch_bounds__(256) k_edge_in_tiles(const float* __restrict__
     if (in) hot = hot && ((ones == 1 && zeros == de_in - 1) || zeros == de_in);
     const int k = (in && i != j && nm[b * n + i] && nm[b * n + j]) ? c : de_in + 1;
     cls[ri][cj] = k;
-    if (in) atomicAdd(&sh[k], 1);
+    // the tile's pairs per table row: one vote per row instead of a thousand LDS atomics on ten addresses
+    for (int kk = 0; kk <= de_in + 1; ++kk) {
+      const int cnt = __popcll(__ballot(in && k == kk));
+      if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&sh[kk], cnt);
+    }
   }
   bool bad = false;
   {
     const int vw = min(32, n - it * 32) * de_in;
-    if (vec && 32 * W4 <= UN_T * 256) {                // tile (jt, it): rows j, columns i; same batched loads
-      float4 q[UN_T];
-#pragma unroll
-      for (int u = 0; u < UN_T; ++u) {
-        const int t = min((int)threadIdx.x + u * 256, 32 * W4 - 1);
-        const int rj = t / W4, o = (t - rj * W4) * 4;
-        q[u] = *reinterpret_cast<const float4*>(base + ((size_t)min(jt * 32 + rj, n - 1) * n + it * 32) * de_in + max(min(o, vw - 4), 0));
-      }
+    if (batched) {                                     // tile (jt, it): rows j, columns i (loaded above)
 #pragma unroll
       for (int u = 0; u < UN_T; ++u) {
         const int t = threadIdx.x + u * 256;
         const int rj = t / W4, o = (t - rj * W4) * 4;
         if (t < 32 * W4 && jt * 32 + rj < n && o < vw) {
-          const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+          const float v[4] = {qm[u].x, qm[u].y, qm[u].z, qm[u].w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int ci = (o + k) / de_in, c = (o + k) - ci * de_in;
