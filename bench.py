@@ -372,6 +372,7 @@ def main():
     all_t = torch.arange(51, device=dev)[:, None, None].expand(-1, B, 1).contiguous()
     all_y = all_t.float() * 5
     state['call'] = 0
+    holders = [(torch.empty(B, n, kx, device=dev), data.E.float().clone()) for _ in range(2)]
 
     def step():
         t = state['t']
@@ -380,8 +381,11 @@ def main():
         state['call'] += 1
         # what sample_one_batch runs per step: denoiser forward with the edge half of posterior / draw / apply_mask drawn inside its
         # output kernel (per-chain counter noise, seeds from `gen`), the node half behind the node output path
+        # (as sample_one_batch: the state alternates between two holders that start as the condition, so the pairs apply_mask keeps fixed
+        # are not written again)
+        out = holders[1] if z_t.E.data_ptr() == holders[0][1].data_ptr() else holders[0]
         zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, chain_seeds=seeds, call=state['call'],
-                                        t_int=t if TABLE_PREFETCH else None)
+                                        t_int=t if TABLE_PREFETCH else None, out=out, out_holds_condition=True)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     'da_x_out_finish': 'i:pipipppiiip',
     'da_edge_out': 'i:ppipppppiiiiip',
     'da_edge_out_tiles': 'i:ppipppppiiiiip', 'da_edge_out_sample': 'i:ppipppppppppfppqpppiiiiip',
+    'da_edge_out_sample_ex': 'i:ppipppppppppfppqpppiiiiiip',
     'da_extra_adjacency': 'i:pppppppiiip',
     'da_extra_cycles': 'i:ppppppiip',
     'da_extra_eigen': 'i:ppqqppppppiip',

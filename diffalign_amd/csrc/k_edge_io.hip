@@ -450,6 +450,7 @@ struct OutSampleArgs {
   const float* zt; const uint8_t* nm; const float* Qt; const float* Qsb; const float* Qtb; float temp;
   const float* noise; const int64_t* seeds; unsigned long long stream;
   const float* orig; const uint8_t* me; float* zs;
+  int keep_fixed;      // zs already holds the condition's values at the pairs that are not free to diffuse: they are not written
 };
 template <int DE, int HE, bool SAMPLE>
 __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __restrict__ E_h, const float* __restrict__ E_in, int de_in,
@@ -466,7 +467,6 @@ __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __re
   float* sB = reinterpret_cast<float*>(smem + WB);      // [32 rows j][32 columns i][8]
   float* sRow = sB + 32 * 32 * 8;                       // [wave][32 * 8]: one output row of tile (it, jt) per wave
   const bool vec4 = ((n * Ke) & 3) == 0 && (reinterpret_cast<uintptr_t>(E_o) & 15) == 0;   // rows of E_o start 16-byte aligned
-  for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += OT_THR) sW[t] = blob[t];
   const uint4* sW0 = sW; const uint4* sW1 = sW + C::HT * C::KS1 * 64;
   const float* sP = reinterpret_cast<const float*>(sW + C::OUT_FR * 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -489,6 +489,14 @@ __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __re
       sFree[w][threadIdx.x & 31] = (q < n && sa.me) ? sa.me[gb + q] : 1;
     }
   }
+  if constexpr (SAMPLE) {
+    if (sa.keep_fixed) {                                   // a tile pair without a free pair has nothing to do at all: leave before the weights are fetched
+      __syncthreads();
+      const unsigned long long fb0 = __ballot(sFree[lane >> 5][lane & 31] != 0);
+      if ((fb0 & 0xffffffffull) == 0 || (fb0 >> 32) == 0) return;
+    }
+  }
+  for (int t = threadIdx.x; t < (int)(C::OUT_BYTES / 16); t += OT_THR) sW[t] = blob[t];
   __syncthreads();                                         // weights, sSrc, sNm, sFree
   // SAMPLE: a pair whose endpoints are not both free to diffuse takes the condition's value (apply_mask), so its logits are never
   // looked at: rows i / j that are not free are neither loaded nor evaluated, and a tile pair without a free row on either side goes
@@ -638,6 +646,7 @@ __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __re
     // for its own load (14 dependent round trips per tile, about half of this kernel's time at B = 64, n = 300).
     constexpr int W = 32 * OT_K, UNW = 7;
     const float* og = sa.orig ? sa.orig : sa.zt;               // without a condition every pair is free and the value read is not used
+    const bool keep = sa.keep_fixed != 0;                      // (wave-uniform) the holder already has the condition's values: free pairs only
     auto write_tile = [&](const bool mirrored) {
       for (int t0 = threadIdx.x; t0 < 32 * W; t0 += OT_THR * UNW) {
         float ov[UNW]; bool ok[UNW], fr[UNW], hot[UNW]; size_t qq[UNW];
@@ -652,11 +661,11 @@ __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __re
           fr[u] = sFree[0][ri] && sFree[1][cj];
           hot[u] = k == c;
           qq[u] = (base + (mirrored ? (size_t)j * n + i : (size_t)i * n + j)) * OT_K + k;
-          ov[u] = og[ok[u] ? qq[u] : base * OT_K];           // unconditional (a predicated load would make every later wait a vmcnt(0))
+          ov[u] = keep ? 0.f : og[ok[u] ? qq[u] : base * OT_K];   // unconditional per lane (a predicated load would make every later wait a vmcnt(0))
         }
 #pragma unroll
         for (int u = 0; u < UNW; ++u)
-          if (ok[u]) sa.zs[qq[u]] = fr[u] ? (hot[u] ? 1.f : 0.f) : ov[u];
+          if (ok[u] && (fr[u] || !keep)) sa.zs[qq[u]] = fr[u] ? (hot[u] ? 1.f : 0.f) : ov[u];
       }
     };
 #ifndef EXP_OT_NOWRITE
@@ -899,10 +908,12 @@ int da_edge_out_tiles(const void* E_h, const float* E_in, int de_in, const void*
 // as da_edge_out_tiles followed by da_posterior_sample's edge half (draw-only form) gives -- same logits, same posterior arithmetic,
 // same race: bit-identical z_s for the same noise.  Noise: noise_E (B,n,n,7) Exp(1) (upper triangle read), or NULL with chain_seeds (B)
 // and `call`: the values da_counter_exp_noise(chain_seeds, call) would put there, generated in registers.  The logits are not written.
-int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1, const float* skip2,
-                       const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
-                       float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
-                       float* zs_E, int B, int n, int de, int he, int ke, void* stream) {
+int da_edge_out_sample_ex(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1, const float* skip2,
+                          const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
+                          float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
+                          float* zs_E, int B, int n, int de, int he, int ke, int flags, void* stream) {
+  DA_CHECK_ARG((flags & ~1) == 0, "da_edge_out_sample_ex: unknown flags %d", flags);
+  DA_CHECK_ARG(!(flags & 1) || (mask_e && orig_E), "da_edge_out_sample_ex: flag 1 (fixed pairs kept) needs a free mask and the condition");
   DA_CHECK_ARG(ke == OT_K && ke <= de_in, "da_edge_out_sample: built for %d edge classes (got %d, input width %d)", OT_K, ke, de_in);
   DA_CHECK_ARG(!(src && (!skip1 || !skip2)), "da_edge_out_sample: skip connection needs both scale pointers");
   DA_CHECK_ARG(zt_E && node_mask && Qt_e && Qsb_e && Qtb_e && zs_E, "da_edge_out_sample: null pointer");
@@ -911,7 +922,7 @@ int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void
   if (B == 0 || n == 0) return DA_OK;
   const int nt = (n + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
-  OutSampleArgs sa{zt_E, node_mask, Qt_e, Qsb_e, Qtb_e, temp_e, noise_E, chain_seeds, 2ull * (unsigned long long)call + 1ull, orig_E, mask_e, zs_E};
+  OutSampleArgs sa{zt_E, node_mask, Qt_e, Qsb_e, Qtb_e, temp_e, noise_E, chain_seeds, 2ull * (unsigned long long)call + 1ull, orig_E, mask_e, zs_E, flags & 1};
   if (de == 64 && he == 128)
     k_edge_out_tiles<64, 128, true><<<dim3(nt * (nt + 1) / 2, B), OT_THR, (EdgeIoCfg<64, 128>::OUT_BYTES + 15) / 16 * 16 + (32 * 32 * 8 + OT_NW * 32 * 8) * sizeof(float), s>>>(
         (const bf16_t*)E_h, E_in, de_in, (const uint4*)blob, src, skip1, skip2, nullptr, n, ke, sa);
@@ -921,6 +932,13 @@ int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void
   else { da_set_error("da_edge_out_sample: dims (de=%d, hidden_mlp E=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   DA_CHECK_LAUNCH("da_edge_out_sample");
   return DA_OK;
+}
+int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1, const float* skip2,
+                       const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
+                       float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
+                       float* zs_E, int B, int n, int de, int he, int ke, void* stream) {
+  return da_edge_out_sample_ex(E_h, E_in, de_in, blob, src, skip1, skip2, zt_E, node_mask, Qt_e, Qsb_e, Qtb_e, temp_e, noise_E, chain_seeds, call,
+                               orig_E, mask_e, zs_E, B, n, de, he, ke, 0, stream);
 }
 
 }  // extern "C"

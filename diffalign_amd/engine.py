@@ -534,11 +534,12 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         main.wait_event(align_done)                  # the skip connection's index (node stream of the input stage; long done)
     if step is not None:
         c = step
-        L.check(lib.da_edge_out_sample(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2),
-                                       L.ptr(c['zt_E']), L.ptr(nm), L.ptr(c['Qt_e']), L.ptr(c['Qsb_e']), L.ptr(c['Qtb_e']),
-                                       C.c_float(c['temp'][1]), L.ptr(c['noise_E']), L.ptr(c['seeds']),
-                                       int(c['call']), L.ptr(c['orig_E']), L.ptr(c['me']), L.ptr(c['zs_E']), _i(B), _i(n), _i(pm.de), _i(pm.he),
-                                       _i(pm.ke), S), 'da_edge_out_sample')
+        keep = 1 if c.get('keep_fixed') and c['me'] is not None and c['orig_E'] is not None else 0
+        L.check(lib.da_edge_out_sample_ex(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2),
+                                          L.ptr(c['zt_E']), L.ptr(nm), L.ptr(c['Qt_e']), L.ptr(c['Qsb_e']), L.ptr(c['Qtb_e']),
+                                          C.c_float(c['temp'][1]), L.ptr(c['noise_E']), L.ptr(c['seeds']),
+                                          int(c['call']), L.ptr(c['orig_E']), L.ptr(c['me']), L.ptr(c['zs_E']), _i(B), _i(n), _i(pm.de), _i(pm.he),
+                                          _i(pm.ke), _i(keep), S), 'da_edge_out_sample_ex')
     else:
         L.check(lib.da_edge_out_tiles(L.ptr(Eh), L.ptr(E), _i(pm.de_in), L.ptr(pm.out_E), L.ptr(src), L.ptr(es1), L.ptr(s2), L.ptr(Eo),
                                       _i(B), _i(n), _i(pm.de), _i(pm.he), _i(pm.ke), S), 'da_edge_out_tiles')

@@ -107,6 +107,7 @@ class SamplingMixin:
             T_loop = range(0)
         else:
             T_loop = range(T_eval, 0, -1)
+        holders = None
         for t_int in T_loop:
             t_array = all_t[t_int]
             z_t.eig_cache, z_t.pad_noise = eig_cache, pad_noise            # read by compute_extra_data; not carried by get_new_object
@@ -114,8 +115,14 @@ class SamplingMixin:
             s_int = t_int - 1
             record = recording and (s_int % log_every_t == 0 or s_int == self.T - 1)
             if not record and not guided:                                  # the whole step as one call (fused where the model allows)
+                # the state alternates between two holders that start as the condition: the pairs that are not free to diffuse have
+                # the condition's value at every step (apply_mask), so the fused step writes the free pairs only
+                if holders is None:
+                    holders = [(torch.empty(B, n, dense_data.X.shape[-1], device=device), dense_data.E.float().clone()) for _ in range(2)]
+                out = holders[1] if z_t.E.data_ptr() == holders[0][1].data_ptr() else holders[0]
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
-                                                orig=dense_data, node_masks=masks, t_int=t_int, **nz(step=True))
+                                                orig=dense_data, node_masks=masks, t_int=t_int, out=out, out_holds_condition=True,
+                                                **nz(step=True))
                 z_t.X, z_t.E = zsX, zsE
                 z_t = fix(z_t)
                 continue

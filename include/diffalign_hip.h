@@ -403,6 +403,15 @@ int da_edge_out_sample(const void* E_h, const float* E_in, int de_in, const void
                        const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e, const float* Qtb_e,
                        float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call, const float* orig_E, const uint8_t* mask_e,
                        float* zs_E, int B, int n, int de, int he, int ke, void* stream);
+/* da_edge_out_sample with flags.  flags & 1: zs_E already holds the condition's values at every pair that is not free to diffuse
+ * (apply_mask, utils/graph.py:411-470, gives those pairs the same value at every step of a chain, so a caller that alternates
+ * between two state buffers -- diffalign_amd/graphs.py, sampling.py -- has them in place after the first two steps): only the
+ * free pairs are written, and tile pairs without a free pair are not touched at all.  Needs mask_e and orig_E. */
+int da_edge_out_sample_ex(const void* E_h, const float* E_in, int de_in, const void* blob, const int* src, const float* skip1,
+                          const float* skip2, const float* zt_E, const uint8_t* node_mask, const float* Qt_e, const float* Qsb_e,
+                          const float* Qtb_e, float temp_e, const float* noise_E, const int64_t* chain_seeds, long long call,
+                          const float* orig_E, const uint8_t* mask_e, float* zs_E, int B, int n, int de, int he, int ke, int flags,
+                          void* stream);
 /* ---- extra input features of the denoiser (reference: CPU round trip at every step,
  * diffusion/diffusion_abstract.py:350-372).  The two adjacency powers and the batched symmetric eigendecomposition between
  * these calls are library routines (torch.bmm, torch.linalg.eigh on the device; diffalign_amd/extra_features.py). ---- */

@@ -33,6 +33,21 @@ def _both(model, data, z_t, t, pos, masks, **noise_kw):
     zsX2, zsE2, pred_n = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
                                             want_logits=True, **noise_kw)
     assert torch.equal(pred_n.E, pred.E) and torch.equal(zsX2, rX) and torch.equal(zsE2, rE)
+    # out= / out_holds_condition: a holder that already has the condition's values at the pairs that are not free to diffuse receives the
+    # free pairs only (da_edge_out_sample_ex flag 1) and ends up as the same z_s; the pairs that are not free are really not written
+    # (a marker value survives there), the free ones all are
+    outX, outE = torch.empty_like(rX), data.E.float().clone()
+    zsX3, zsE3, _ = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                                       out=(outX, outE), out_holds_condition=True, **noise_kw)
+    assert zsE3.data_ptr() == outE.data_ptr() and torch.equal(zsX3, rX) and torch.equal(zsE3, rE)
+    free = masks[1].bool() & z_t.node_mask.bool() if masks[1].dtype != torch.bool else masks[1] & z_t.node_mask.bool()
+    pair_free = free[:, :, None] & free[:, None, :]
+    outE = torch.full_like(rE, -5.0)
+    model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                       out=(outX, outE), out_holds_condition=True, **noise_kw)
+    written = (outE != -5.0).all(-1)
+    assert not bool((written & ~masks[1].bool()[:, :, None] ).any()) and not bool((written & ~masks[1].bool()[:, None, :]).any())
+    assert torch.equal(outE[pair_free], rE[pair_free])
     return rX, rE
 
 
