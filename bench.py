@@ -373,6 +373,8 @@ def main():
     all_y = all_t.float() * 5
     state['call'] = 0
     holders = [(torch.empty(B, n, kx, device=dev), data.E.float().clone()) for _ in range(2)]
+    # per chain, as sample_one_batch: the last layer computes the rows of free nodes only (DA_LAST_ROWS=0: A/B switch)
+    last_rows = graph.free_rows(masks) if os.environ.get('DA_LAST_ROWS', '1') != '0' else None
 
     def step():
         t = state['t']
@@ -385,7 +387,7 @@ def main():
         # are not written again)
         out = holders[1] if z_t.E.data_ptr() == holders[0][1].data_ptr() else holders[0]
         zsX, zsE, _ = model.reverse_step(z_t, t_arr, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, chain_seeds=seeds, call=state['call'],
-                                        t_int=t if TABLE_PREFETCH else None, out=out, out_holds_condition=True)
+                                        t_int=t if TABLE_PREFETCH else None, out=out, out_holds_condition=True, last_rows=last_rows)
         z_t.X, z_t.E = zsX, zsE
         state['t'] = t - 1 if t > 1 else 50
 
@@ -445,7 +447,10 @@ def main():
         dt = time.perf_counter() - t0
     ev = engine.PROFILE_EVENTS if not use_graph else ev_eager
     engine.PROFILE_EVENTS = None
-    edge_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+    ev_ms = [(a.elapsed_time(b), share) for a, b, share in ev]
+    edge_ms = sum(m for m, _ in ev_ms) / max(1, len(ev_ms))              # mean over ALL launches (what rocprofv3 --stats averages)
+    edge_share = sum(sh for _, sh in ev_ms) / max(1, len(ev_ms))          # mean share of the query rows a launch computes (last layer: free nodes only)
+    full_ms = [m for m, sh in ev_ms if sh == 1.0]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -455,8 +460,9 @@ def main():
     # roofline of the dominant kernel (k_edge_layer, one launch per layer): algorithmic bytes = each 64-wide bf16 edge
     # row read once + written once; algorithmic FLOPs = 131,072 per pair
     pairs = B * n * n
-    bytes_launch = pairs * 64 * 2 * 2
-    flops_launch = pairs * 131072.0
+    # (the mean launch computes `edge_share` of the rows: the last layer of a fused step leaves out the rows of nodes that are not free)
+    bytes_launch = pairs * 64 * 2 * 2 * edge_share
+    flops_launch = pairs * 131072.0 * edge_share
     t_s = edge_ms * 1e-3
     tf = flops_launch / t_s / 1e12 if t_s > 0 else 0.0
     gbs = bytes_launch / t_s / 1e9 if t_s > 0 else 0.0
@@ -479,7 +485,9 @@ def main():
         pass
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
-            'algorithmic_bytes_per_launch': bytes_launch, 'avg_launch_ms': edge_ms, 'launches_timed': len(ev),
+            'algorithmic_bytes_per_launch': bytes_launch, 'algorithmic_flops_per_launch': flops_launch, 'avg_launch_ms': edge_ms,
+            'launches_timed': len(ev), 'mean_share_of_rows_per_launch': edge_share,
+            'avg_full_launch_ms': (sum(full_ms) / len(full_ms)) if full_ms else None,
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
     if traffic_note:
         roof['traffic_note'] = traffic_note

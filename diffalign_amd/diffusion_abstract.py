@@ -139,7 +139,7 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
                            mol_assignments=noisy_data.mol_assignments)
 
     def reverse_step(self, z_t, t_array, pos_encodings=None, transition_model=None, temperature=(1.0, 1.0), noise=None, chain_seeds=None,
-                     call=0, orig=None, node_masks=None, generator=None, want_logits=False, t_int=None, tables=None, out=None, out_holds_condition=False):
+                     call=0, orig=None, node_masks=None, generator=None, want_logits=False, t_int=None, tables=None, out=None, out_holds_condition=False, last_rows=None):
         """One reverse step p(z_s | z_t) (diffusion/sampling.py:76-86,165-178): denoiser forward + posterior + categorical draw +
         apply_mask.  With 7 edge classes the edge half is drawn inside the denoiser's output kernel (da_edge_out_sample; the
         (B,n,n,7) logits and noise tensors never reach HBM); otherwise forward() + helpers.posterior_sample.  Both give the same
@@ -147,7 +147,10 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         `t_int`: the step number when all graphs share it (then t_array is not read for the tables).
         `out` = (X, E): preallocated fp32 tensors that receive z_s (and are returned); they must not be z_t's.
         `out_holds_condition`: the caller's promise that out's E already has the condition's values (`orig`) at every pair that is not
-        free to diffuse -- true for a buffer that held an earlier state of the same chain: those pairs are then not written again."""
+        free to diffuse -- true for a buffer that held an earlier state of the same chain: those pairs are then not written again.
+        `last_rows`: graph.free_rows(node_masks, node_mask) of this chain (computed once per chain: one host sync): the denoiser's last
+        layer then computes the query rows of free nodes only -- nothing else of it is read by the fused step (pred.X is then defined on
+        those rows only)."""
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
         if tables is not None:       # (Q_t, Qbar_{t-1}, Qbar_t) of this step laid out by the caller (graphs.GraphedChain)
@@ -158,7 +161,7 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
             Qt, Qsb, Qtb = tm.get_Qt(t_array), tm.get_Qt_bar(t_array - 1), tm.get_Qt_bar(t_array)
         if self._net().supports_fused_step() and not self._net()._differentiable() and not want_logits:
             ctx = helpers.reverse_step_ctx(z_t, Qt, Qsb, Qtb, temperature, noise, chain_seeds, call, orig, node_masks, generator, out=out,
-                                           out_holds_condition=out_holds_condition)
+                                           out_holds_condition=out_holds_condition, last_rows=last_rows)
             pred = self.forward(z_t=z_t, pos_encodings=pos_encodings, step=ctx)
             return ctx['zs_X'], ctx['zs_E'], pred
         B, n, kx = z_t.X.shape

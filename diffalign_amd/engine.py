@@ -59,7 +59,7 @@ def use_stats_tail(n: int) -> bool:
 CAPTURE_SIDE_STREAMS = True   # under HIP-graph capture the side streams join the capture through their events (False: one stream)
 TABLE_IN = True        # first edge layer reads its input rows from the input stage's table (da_edge_in_classes / da_edge_layer_table)
 SPLIT_TAIL = True      # load-balance the edge kernel's last round (da_edge_split_scratch_bytes); False: whole rows only
-PROFILE_EVENTS = None   # bench.py sets this to a list: (start, end) torch.cuda.Event pairs around each da_edge_layer launch
+PROFILE_EVENTS = None   # bench.py sets this to a list: (start event, end event, share of the query rows computed) per da_edge_layer launch
 
 
 def _i(v):
@@ -201,15 +201,18 @@ def _qkv_buffers(pm: PackedModel, B, n, dev):
     return torch.empty(B * n, pm.dx if pm.fused_qkv else 3 * pm.dx, device=dev), kvf
 
 
-def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None):
+def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None, rows=None):
     """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out.
-    `table` = (cls_map, scratch) of da_edge_in_classes: the first layer reads its input rows from the input stage's table."""
+    `table` = (cls_map, scratch) of da_edge_in_classes: the first layer reads its input rows from the input stage's table.
+    `rows`: int32 tensor of the query rows b n + i to compute, ascending (da_edge_layer_ex): the others get zeros in newX_in and
+    nothing in E' (the last layer of a fused reverse step: only the rows of nodes that are free to diffuse are read again)."""
     dev, dx, de, lib, S = E_bf16.device, pm.dx, pm.de, L.lib(), L.stream()
     ye2p1, ebias, yx1, yx2p1 = film
     E_out = torch.empty_like(E_bf16)
-    nsplit = lib.da_edge_split_scratch_bytes(_i(B), _i(n), _i(dx)) if SPLIT_TAIL else 0
+    n_rows = int(rows.numel()) if rows is not None else B * n
+    nsplit = lib.da_edge_split_scratch_bytes_rows(C.c_longlong(n_rows), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
-    newX_in = torch.empty(B * n, dx, device=dev)
+    newX_in = torch.empty(B * n, dx, device=dev) if rows is None else torch.zeros(B * n, dx, device=dev)
     ticket = pm.ticket if stats_out is not None else None
     profile = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
     if profile:
@@ -218,7 +221,12 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
             L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
             C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
             L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
-    if table is not None:
+    if rows is not None:
+        assert table is None and rows.dtype == torch.int32 and rows.is_contiguous()
+        N_ = L.ptr(None)
+        L.check(lib.da_edge_layer_ex(*args, L.ptr(stats_out), _i(stats_out.shape[1] if stats_out is not None else 0), L.ptr(ticket),
+                                     N_, N_, _i(0), L.ptr(rows), _i(n_rows), S), 'da_edge_layer_ex')
+    elif table is not None:
         assert stats_out is None
         L.check(lib.da_edge_layer_table(*args, L.ptr(table[0]), L.ptr(table[1]), _i(pm.de_in), S), 'da_edge_layer_table')
     elif stats_out is not None:
@@ -226,7 +234,7 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
     else:
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
     if profile:
-        ev1.record(); PROFILE_EVENTS.append((ev0, ev1))
+        ev1.record(); PROFILE_EVENTS.append((ev0, ev1, n_rows / float(B * n)))
     return E_out, newX_in, split
 
 
@@ -337,7 +345,7 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre, table0=None):
+def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre, table0=None, last_rows=None):
     """The layer stack with the NODE chain on the caller's stream (merge, node tail of layer l, q/k/v of layer l+1 directly behind the
     edge kernel and in front of the next one: no cross-stream event on it) and the y chain on the side stream (edge kernel -> event ->
     y_update(l) + FiLM(l+1) [+ the separate statistics pass of small graphs] -> event the next edge kernel waits on).  Since the y
@@ -366,7 +374,8 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
         qkv_next = _qkv_buffers(pm, B, n, dev) if nxt is not None else None
         xst_next = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev) if nxt is not None else None
         xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
-        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None)
+        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None,
+                                       rows=last_rows if nxt is None and li > 0 else None)
         ev_edge = main.record_event()
         with torch.cuda.stream(side):                # y chain
             side.wait_event(ev_edge)
@@ -499,7 +508,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
     else:
-        Xh, Eh, yh = _layers_node_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre, table0=table0)
+        Xh, Eh, yh = _layers_node_on_main(pm, Xh, Eh, yh, nm, st0, film0, y_done0, B, n, main, side, side2, pre, table0=table0,
+                                          last_rows=step.get('last_rows') if step is not None else None)
     # ---- output stage (the node output path beside the edge output stage)
     h1 = torch.empty(R, pm.hx, device=dev)
     lin = torch.empty(R, pm.kx, device=dev)

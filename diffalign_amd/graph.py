@@ -65,6 +65,14 @@ def get_node_masks(orig: PlaceHolder, atom_decoder, bond_decoder, mask_nodes, ma
     return mx.view(torch.bool), me.view(torch.bool)
 
 
+def free_rows(node_masks) -> torch.Tensor:
+    """Row numbers b n + i (int32, ascending) of the nodes whose class or whose edges may change at a reverse step (get_node_masks'
+    pair).  Every pair with another endpoint keeps the condition's value (apply_mask, graph.py:411-470), so the denoiser's last layer
+    has nothing to compute for the other rows (DiscreteDenoisingDiffusion.reverse_step last_rows=).  One host sync: once per chain."""
+    need = node_masks[0].bool() | node_masks[1].bool()
+    return torch.nonzero(need.reshape(-1)).squeeze(1).to(torch.int32).contiguous()
+
+
 def from_mask_to_maskX_maskE(mask_nodes, mask_edges, shape_X, shape_E):
     """graph.py:607-619 (expanded views, built only when a caller asks for the dense masks)."""
     mask_X = mask_nodes.unsqueeze(-1).expand(-1, -1, shape_X[-1])

@@ -84,7 +84,7 @@ def posterior_sample(pred_X, pred_E, z_t: PlaceHolder, Qt: PlaceHolder, Qsb: Pla
 
 def reverse_step_ctx(z_t: PlaceHolder, Qt: PlaceHolder, Qsb: PlaceHolder, Qtb: PlaceHolder, temperature=(1.0, 1.0),
                      noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, chain_seeds: Optional[torch.Tensor] = None, call: int = 0,
-                     orig: Optional[PlaceHolder] = None, node_masks=None, generator=None, out=None, out_holds_condition=False) -> dict:
+                     orig: Optional[PlaceHolder] = None, node_masks=None, generator=None, out=None, out_holds_condition=False, last_rows=None) -> dict:
     """What engine.model_forward(step=...) needs to draw z_s behind the denoiser's output stage (the fused form of posterior_sample).
     Noise, in this order of preference: explicit Exp(1) tensors `noise` = (qX, qE); per-chain counter noise (`chain_seeds`, `call`:
     the edge half generates da_counter_exp_noise's values in registers, never materialising the (B,n,n,ke) tensor); otherwise
@@ -117,7 +117,8 @@ def reverse_step_ctx(z_t: PlaceHolder, Qt: PlaceHolder, Qsb: PlaceHolder, Qtb: P
         mx, me = L.as_u8(node_masks[0]), L.as_u8(node_masks[1])
     return dict(zt_X=f(z_t.X), zt_E=f(z_t.E), Qt_x=f(Qt.X), Qsb_x=f(Qsb.X), Qtb_x=f(Qtb.X), Qt_e=f(Qt.E), Qsb_e=f(Qsb.E), Qtb_e=f(Qtb.E),
                 temp=(float(temperature[0]), float(temperature[1])), noise_X=qX, noise_E=qE, seeds=seeds, call=int(call),
-                orig_X=oX, orig_E=oE, mx=mx, me=me, zs_X=zsX, zs_E=zsE, keep_fixed=bool(out_holds_condition and out is not None))
+                orig_X=oX, orig_E=oE, mx=mx, me=me, zs_X=zsX, zs_E=zsE, keep_fixed=bool(out_holds_condition and out is not None),
+                last_rows=last_rows if node_masks is not None else None)
 
 
 def get_p_zs_given_zt(transition_model, t_array, pred, z_t, return_prob=False, temperature_scaling=1.0, noise=None):

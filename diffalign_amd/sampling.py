@@ -107,7 +107,7 @@ class SamplingMixin:
             T_loop = range(0)
         else:
             T_loop = range(T_eval, 0, -1)
-        holders = None
+        holders = last_rows = None
         for t_int in T_loop:
             t_array = all_t[t_int]
             z_t.eig_cache, z_t.pad_noise = eig_cache, pad_noise            # read by compute_extra_data; not carried by get_new_object
@@ -120,9 +120,11 @@ class SamplingMixin:
                 if holders is None:
                     holders = [(torch.empty(B, n, dense_data.X.shape[-1], device=device), dense_data.E.float().clone()) for _ in range(2)]
                 out = holders[1] if z_t.E.data_ptr() == holders[0][1].data_ptr() else holders[0]
+                if last_rows is None:                                      # (one host sync per chain)
+                    last_rows = graph.free_rows(masks)
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
                                                 orig=dense_data, node_masks=masks, t_int=t_int, out=out, out_holds_condition=True,
-                                                **nz(step=True))
+                                                last_rows=last_rows, **nz(step=True))
                 z_t.X, z_t.E = zsX, zsE
                 z_t = fix(z_t)
                 continue

@@ -48,6 +48,16 @@ def _both(model, data, z_t, t, pos, masks, **noise_kw):
     written = (outE != -5.0).all(-1)
     assert not bool((written & ~masks[1].bool()[:, :, None] ).any()) and not bool((written & ~masks[1].bool()[:, None, :]).any())
     assert torch.equal(outE[pair_free], rE[pair_free])
+    # last_rows: the last layer computes the query rows of free nodes only (da_edge_layer_ex rowmap): the same z_s, and the node logits
+    # of those rows are the same bits
+    from diffalign_amd import graph as G
+    rows = G.free_rows(masks)
+    assert 0 < rows.numel() < B * n
+    zsX4, zsE4, pred4 = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                                           last_rows=rows, **noise_kw)
+    assert torch.equal(zsX4, rX) and torch.equal(zsE4, rE)
+    need = (masks[0].bool() | masks[1].bool())
+    assert torch.equal(pred4.X[need], pred.X[need]) and bool(torch.isfinite(pred4.X).all())
     return rX, rE
 
 

@@ -30,6 +30,6 @@ engine.PROFILE_EVENTS = []
 for _ in range(iters):
     engine.layer_forward(pm, pm.layers[0], X, E, y, nm, st, B, n)
 torch.cuda.synchronize()
-ms = sum(a.elapsed_time(b) for a, b in engine.PROFILE_EVENTS) / iters
+ms = sum(e[0].elapsed_time(e[1]) for e in engine.PROFILE_EVENTS) / iters
 pairs = B * n * n
 print(f'edge_layer B={B} n={n}: {ms:.3f} ms/launch  {pairs*131072/ms/1e9:.1f} TFLOP/s  {pairs*256/ms/1e6:.1f} GB/s algorithmic')

@@ -28,7 +28,7 @@ bench.main()
 ev = events['ev']
 torch.cuda.synchronize()
 L = 9
-ms = [a.elapsed_time(b) for a, b in ev]
+ms = [e[0].elapsed_time(e[1]) for e in ev]
 for l in range(L):
     v = ms[l::L]
     print(f'layer {l}: {sum(v) / len(v):.4f} ms  (min {min(v):.4f}, max {max(v):.4f})')
