@@ -505,7 +505,10 @@ def main():
                                        f'nodes) padded to n={n}, batch {B}/GPU, same network and step'),
                           'extra_features': 'given as inputs (SURVEY 8d)' if args.extra_features == 'inputs' else 'computed on the device inside the step',
                           'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)',
-                          'hip_graph_per_step': bool(use_graph)},
+                          'hip_graph_per_step': bool(use_graph),
+                          'dead_work_elided': ('as sample_one_batch: with the product side fixed by the mask, the last layer computes the query rows of the '
+                                               'free nodes only and the fixed pairs of z_s are not rewritten -- z_s is bit-identical '
+                                               '(tests/test_gpu_fused_step.py); DA_LAST_ROWS=0 computes every row') if last_rows is not None and not use_graph else None},
                'roofline': roof}
         if world == 1 and not args.no_loop and args.extra_features == 'inputs' and not use_graph:
             out['loop'] = loop_object(args, model, step, z_t, data, masks, dev)

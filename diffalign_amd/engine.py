@@ -364,7 +364,10 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
     keep = []
     for li, lw in enumerate(pm.layers):
         nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
-        tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) else None
+        # the last layer of a fused reverse step with a row list: its y output is read by nobody (the step returns z_s), so neither the
+        # Etoy statistics of its input (the edge kernel's tail) nor its y update are computed; the stream joins stay as they are
+        no_y = nxt is None and li > 0 and last_rows is not None
+        tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) and not no_y else None
         st = st0 if li == 0 else (tail if tail is not None else st_pass)
         st_next = (torch.empty(B, stat_chunks(n), 4, pm.de, dtype=torch.float32, device=dev)
                    if nxt is not None and not use_stats_tail(n) else None)
@@ -381,7 +384,8 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
             side.wait_event(ev_edge)
             if xs_done is not None:
                 side.wait_event(xs_done)             # xy of this layer (recorded one edge kernel ago)
-            y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
+            if not no_y:
+                y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
             if st_next is not None:
                 edge_stats(E_next, B, n, pm.de, out=st_next)
             ev_y = side.record_event()
@@ -398,7 +402,7 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
         keep.append((Xh, Eh, yh, film, Qm, kvf, xst, xy, st, newX_in, split))
         if len(keep) > 2:
             keep.pop(0)                              # layer l-2: every reader of its buffers has been joined since
-        Xh, Eh, yh, film, xst, xy, st_pass = X_next, E_next, y_next, film_next, xst_next, xy_next, st_next
+        Xh, Eh, yh, film, xst, xy, st_pass = X_next, E_next, (None if no_y else y_next), film_next, xst_next, xy_next, st_next
         if nxt is not None:
             Qm, kvf = qkv_next
     if xs_done is not None:

@@ -94,7 +94,7 @@ class GraphTransformerWithY(_DenoiserBase):
             return forward_train(self, X, E, y, node_mask, precision=self._unfused_precision()) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, step=step)
-        yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
+        yo = None if yh is None else yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]    # (None: fused step with a row list)
         return Xo, Eo, yo, node_mask
 
 
@@ -139,5 +139,5 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
                                           use_skip=self.p_to_r_skip_connection, step=step,
                                           edge_skip_uniform=self.input_alignment, align_src=src)
-        yo = yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]
+        yo = None if yh is None else yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]    # (None: fused step with a row list)
         return Xo, Eo, yo, node_mask

@@ -58,6 +58,7 @@ def _both(model, data, z_t, t, pos, masks, **noise_kw):
     assert torch.equal(zsX4, rX) and torch.equal(zsE4, rE)
     need = (masks[0].bool() | masks[1].bool())
     assert torch.equal(pred4.X[need], pred.X[need]) and bool(torch.isfinite(pred4.X).all())
+    assert pred4.E is None and (pred4.y is None or len(model.model.tf_layers) == 1)       # the last layer's y is not computed either
     return rX, rE
 
 
