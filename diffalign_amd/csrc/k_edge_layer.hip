@@ -104,6 +104,7 @@ struct EdgeLayerArgs {
   // positions in this list.  null: every row.  (The last layer of a fused reverse step needs only the rows of nodes that are free to
   // diffuse: nobody reads E'[i][.] or newX_in[i] of the others.)
   const int* rowmap; int n_rows;
+  const int* n_rows_dev;  // the list's length read on the device (a launch captured in a HIP graph serves lists of any length); null: n_rows
 };
 
 // One 32-channel block of one 32-pair tile: GEMM1, Y, online softmax, FiLM, transpose, GEMM2 accumulate.
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
   constexpr int NW = NTHREADS / 64;
   const int n = a.n;
   const int NT = (n + 31) / 32;
-  const int R = a.rowmap ? a.n_rows : a.B * n;
+  const int R = a.rowmap ? (a.n_rows_dev ? *a.n_rows_dev : a.n_rows) : a.B * n;
 
   const bf16x8 id0 = ident_frag(0, r, h), id1 = ident_frag(1, r, h);
   bf16x8 onesA;                                         // A operand with ones in the k = 0, 1 columns
@@ -767,7 +768,8 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 // folds the runs of every split row (EdgePart) into the x_out input: newX_in = yx1 + yx2p1 * (sum_r a_r e^{m_r-M}) / (sum_r l_r e^{m_r-M})
 __global__ void __launch_bounds__(256) k_edge_split_merge(const float* split, int slots_per_xcd, const float* yx1, const float* yx2p1,
                                                           float* newX_in, int R, int n, int DX, int grid_blocks, int NW, int max_rem,
-                                                          int tail_old, const int* rowmap) {
+                                                          int tail_old, const int* rowmap, const int* n_rows_dev) {
+  if (n_rows_dev) R = *n_rows_dev;
   const int NT = (n + 31) / 32;
   const int xcd = blockIdx.x / max_rem, rl = blockIdx.x % max_rem;
   const EdgePart part(R, grid_blocks, NW, NT, xcd, true, tail_old != 0);
@@ -915,8 +917,10 @@ int da_kv_pack(const float* K, const float* V, int ldkv, void* out, int B, int n
 // Fused edge side of one XEyTransformerLayer (see file header).  All pointers device; E bf16.
 // bytes of the tail-split scratch da_edge_layer can use for this problem size (0: no split needed)
 long long da_edge_split_scratch_bytes_rows(long long rows, int n, int dx) {
-  if (rows <= 0 || n <= 0 || rows > 0x7fffffffLL) return 0;
+  if (rows == 0 || n <= 0 || rows > 0x7fffffffLL || rows < -0x7fffffffLL) return 0;
   const int NT = (n + 31) / 32;
+  if (rows < 0)          // a row list whose length is read on the device (estimate -rows): room for any number of split rows
+    return (long long)8 * ((edge_grid((int)-rows) >> 3) * (edge_threads() / 64) - 1) * NT * 3 * dx * (long long)sizeof(float);
   return (long long)8 * edge_max_rem((int)rows, n) * NT * 3 * dx * (long long)sizeof(float);
 }
 long long da_edge_split_scratch_bytes(int B, int n, int dx) { return B <= 0 ? 0 : da_edge_split_scratch_bytes_rows((long long)B * n, n, dx); }
@@ -926,24 +930,26 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
                            const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                            long long split_scratch_bytes, float* stats, int stats_nchunk, int* ticket, void* stream,
                            const uint8_t* cls = nullptr, const uint8_t* in_scratch = nullptr, int de_in = 0,
-                           const int* rowmap = nullptr, int n_rows = 0) {
+                           const int* rowmap = nullptr, int n_rows = 0, const int* n_rows_dev = nullptr) {
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   DA_CHECK_ARG(!rowmap || (n_rows >= 0 && (long long)n_rows <= (long long)B * n), "da_edge_layer_ex: n_rows = %d outside 0 .. B n", n_rows);
   if (B == 0 || n == 0 || (rowmap && n_rows == 0)) return DA_OK;
   const int rows = rowmap ? n_rows : B * n, NT = (n + 31) / 32;
   const int grid = edge_grid(rows);
-  const int max_rem = edge_max_rem(rows, n);
+  // (list length on the device: `rows` is the caller's estimate -- it fixes the grid and the shares --, and the split rows are sized for
+  // any length: fewer than the waves of an XCD chunk)
+  const int max_rem = (rowmap && n_rows_dev) ? (grid >> 3) * (edge_threads() / 64) - 1 : edge_max_rem(rows, n);
   float* split = nullptr;
   if (split_scratch && max_rem > 0) {
-    DA_CHECK_ARG(split_scratch_bytes >= da_edge_split_scratch_bytes_rows(rows, n, dx),
+    DA_CHECK_ARG(split_scratch_bytes >= (long long)8 * max_rem * NT * 3 * dx * (long long)sizeof(float),
                  "da_edge_layer: split scratch of %lld B is smaller than da_edge_split_scratch_bytes", split_scratch_bytes);
     split = (float*)split_scratch;
   }
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
                   newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, 1, stats, stats_nchunk, ticket,
                   cls, cls ? reinterpret_cast<const uint4*>(in_scratch + in_table_offset(B)) : nullptr, in_scratch, de_in + 2,
-                  rowmap, n_rows};
+                  rowmap, n_rows, rowmap ? n_rows_dev : nullptr};
   { const EdgeTuning tune = edge_tuning();
     a.stagger = tune.stagger; a.prio = tune.prio; a.skip_dead = tune.skip_dead;
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
@@ -970,7 +976,7 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
   DA_CHECK_LAUNCH("da_edge_layer");
   if (split) {
     k_edge_split_merge<<<8 * max_rem, 256, 0, (hipStream_t)stream>>>(split, max_rem * NT, yx1, yx2p1, newX_in, rows, n, dx, grid,
-                                                                    edge_threads() / 64, max_rem, a.tail_old, rowmap);
+                                                                    edge_threads() / 64, max_rem, a.tail_old, rowmap, rowmap ? n_rows_dev : nullptr);
     DA_CHECK_LAUNCH("da_edge_layer (split merge)");
   }
   return DA_OK;
@@ -1013,18 +1019,20 @@ int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, 
 // The general form: the three entry points above with every optional part as an argument (NULL / 0: absent), and
 //   rowmap[0 .. n_rows): the query rows b n + i to compute, ascending (NULL: all).  The rows left out get neither their row of E_out nor
 //   of newX_in (both stay as they were); the split scratch is sized by da_edge_split_scratch_bytes_rows(n_rows, n, dx).
+//   n_rows_dev (optional): the list's length as an int in device memory, read by the kernels -- n_rows is then the caller's estimate
+//   (grid and shares are chosen for it) and the scratch is sized by da_edge_split_scratch_bytes_rows(-n_rows, n, dx) (any length).
 int da_edge_layer_ex(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                      const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                      const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                      long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, const uint8_t* cls_map,
-                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, void* stream) {
+                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, const int* n_rows_dev, void* stream) {
   DA_CHECK_ARG((stats_partials == nullptr) == (ticket == nullptr) && (stats_partials == nullptr || stats_nchunk >= 1),
                "da_edge_layer_ex: statistics partials and ticket go together");
   DA_CHECK_ARG((cls_map == nullptr) == (in_scratch == nullptr) && (cls_map == nullptr || (de_in >= 1 && de_in <= 8)),
                "da_edge_layer_ex: class map and input scratch go together (1 <= de_in <= 8)");
   return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
                          split_scratch, split_scratch_bytes, stats_partials, stats_nchunk, ticket, stream, cls_map, in_scratch, de_in,
-                         rowmap, n_rows);
+                         rowmap, n_rows, n_rows_dev);
 }
 
 }  // extern "C"

@@ -209,8 +209,13 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
     dev, dx, de, lib, S = E_bf16.device, pm.dx, pm.de, L.lib(), L.stream()
     ye2p1, ebias, yx1, yx2p1 = film
     E_out = torch.empty_like(E_bf16)
-    n_rows = int(rows.numel()) if rows is not None else B * n
-    nsplit = lib.da_edge_split_scratch_bytes_rows(C.c_longlong(n_rows), _i(n), _i(dx)) if SPLIT_TAIL else 0
+    rows_dev = None
+    if isinstance(rows, tuple):                      # (list buffer, its length on the device, an estimate of it): graphs.GraphedChain
+        rows, rows_dev, n_rows = rows
+        n_rows = max(1, min(int(n_rows), B * n))
+    else:
+        n_rows = int(rows.numel()) if rows is not None else B * n
+    nsplit = lib.da_edge_split_scratch_bytes_rows(C.c_longlong(-n_rows if rows_dev is not None else n_rows), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
     newX_in = torch.empty(B * n, dx, device=dev) if rows is None else torch.zeros(B * n, dx, device=dev)
     ticket = pm.ticket if stats_out is not None else None
@@ -225,7 +230,7 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
         assert table is None and rows.dtype == torch.int32 and rows.is_contiguous()
         N_ = L.ptr(None)
         L.check(lib.da_edge_layer_ex(*args, L.ptr(stats_out), _i(stats_out.shape[1] if stats_out is not None else 0), L.ptr(ticket),
-                                     N_, N_, _i(0), L.ptr(rows), _i(n_rows), S), 'da_edge_layer_ex')
+                                     N_, N_, _i(0), L.ptr(rows), _i(n_rows), L.ptr(rows_dev), S), 'da_edge_layer_ex')
     elif table is not None:
         assert stats_out is None
         L.check(lib.da_edge_layer_table(*args, L.ptr(table[0]), L.ptr(table[1]), _i(pm.de_in), S), 'da_edge_layer_table')

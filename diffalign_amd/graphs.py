@@ -20,6 +20,29 @@ CHAIN_GRAPH_MAX_PAIRS = 1_600_000
 CHAIN_GRAPH_CACHE = 3            # shapes kept per model (each holds its graphs' private memory pool)
 
 
+_CAPTURE_READY = set()
+
+
+def _prepare_capture(dev) -> None:
+    """torch creates the generator's graph-safe seed / offset tensors at the first capture of a process and updates them in place at
+    every later one: if that first capture happens under torch.inference_mode (the inference API) they are inference tensors, and the
+    next capture outside it (a sampler under no_grad) fails with 'Inplace update to inference tensor'.  One trivial capture outside
+    inference mode, once per device, before any of ours."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _CAPTURE_READY or torch.cuda.is_current_stream_capturing():
+        return
+    with torch.inference_mode(False):
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            x = torch.zeros(8, device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                x += 1
+        torch.cuda.current_stream(dev).wait_stream(s)
+    _CAPTURE_READY.add(key)
+
+
 def chain_graphs_wanted(B: int, n: int) -> bool:
     if CHAIN_GRAPHS == '0' or torch.cuda.is_current_stream_capturing():
         return False
@@ -44,6 +67,7 @@ class GraphedTrainStep:
         assert optimizer.step_dev is not None, 'GraphedTrainStep needs optim.FlatAdamW(..., device_step=True)'
         assert model.model.training, 'call model.train() first'
         self.model, self.opt, self.group = model, optimizer, group
+        _prepare_capture(example.X.device)
         self.data = example.get_new_object()                 # static copies (get_new_object clones every field)
         self.pos = model.get_pos_encodings(self.data)
         if self.pos is not None:
@@ -137,6 +161,7 @@ class GraphedChain:
         from . import _lib as L
         from .extra_features import EigCache
         dev = data.X.device
+        _prepare_capture(dev)
         B, n, kx = data.X.shape
         self.model, self.temps, self.first_call, self.B, self.n = model, tuple(temps), int(first_call), B, n
         self.pm = model._net()._pack(dev)                    # the packed weights the graphs point at (kept alive; identity = freshness)
@@ -157,6 +182,12 @@ class GraphedChain:
         tm = model.transition_model_eval
         rep = lambda Q: Q[:, None].expand(-1, B, -1, -1).contiguous()
         self.tabs = (rep(tm.Qts_x), rep(tm.Qts_e), rep(tm.Qt_bars_x), rep(tm.Qt_bars_e))   # this object's own: never re-laid-out
+        # query rows the denoiser's last layer computes (graph.free_rows of the loaded chain): the list and its length live in static
+        # buffers and the kernels read the length on the device, so the captured steps serve every chain; the estimate that fixes the
+        # launch geometry at capture time is the first chain's count
+        self.rows = torch.zeros(B * n, dtype=torch.int32, device=dev)
+        self.n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.rows_hint = None
         self.eig = None
         if with_eig_cache:                                   # sized for any fixed block of this shape; filled per chain by load()
             self.eig = EigCache(torch.zeros(B, dtype=torch.int32, device=dev), n)
@@ -179,6 +210,12 @@ class GraphedChain:
         if self.fix_edges is not None:
             self.fix_edges.copy_(fix_edges)
         self.seeds.copy_(seeds)
+        from . import graph
+        rows = graph.free_rows(masks)
+        self.rows[:rows.numel()].copy_(rows)
+        self.n_rows.fill_(int(rows.numel()))
+        if self.rows_hint is None:
+            self.rows_hint = int(rows.numel())
         if pad_noise is not None:                            # drawn per chain only when the extra features' eigensolver runs
             self.pad_noise.copy_(pad_noise)
         ts = self.T_eval if t_start is None else int(t_start)
@@ -207,7 +244,8 @@ class GraphedChain:
         z.y = self.all_y[t]
         m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
                        orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
-                       call=self.first_call + (self.T_eval - t), tables=self._tables(t), out=(zo.X, zo.E), out_holds_condition=True)
+                       call=self.first_call + (self.T_eval - t), tables=self._tables(t), out=(zo.X, zo.E), out_holds_condition=True,
+                       last_rows=(self.rows, self.n_rows, self.rows_hint) if self.rows_hint else None)
         graph.apply_inpainting(zo, self.data, self.fix_nodes, self.fix_edges)
         if not m.cfg.diffusion.diffuse_edges:
             zo.E.copy_(self.data.E)

@@ -134,7 +134,7 @@ def predict_precursors_from_diffalign(product_smiles: str, n_precursors: int = 1
     model, cfg = get_model_and_cfg()
     _ensure_transition_model(model, cfg, diffusion_steps)
     dense_data = smiles_to_dense_data(product_smiles, cfg).to_device(model.device_)
-    with torch.inference_mode():
+    with torch.no_grad():          # (the reference: inference_mode; tensors made there cannot be updated outside it -- the static buffers of cached HIP graphs are)
         final_samples = model.sample_for_condition(dense_data=dense_data, n_samples=n_precursors, inpaint_node_idx=None,
                                                    inpaint_edge_idx=None, device=model.device_)
     final_samples.atom_map_numbers, final_samples.mol_assignments = dense_data.atom_map_numbers, dense_data.mol_assignments
@@ -166,7 +166,7 @@ def predict_with_inpainting(product_smiles: str, previous_sample_data: dict, inp
     if dense_data.E.ndim == 3:
         dense_data.E = F.one_hot(dense_data.E.long(), num_classes=model.Edim_output).float()
     cond_am, cond_mol, cond_nm = dense_data.atom_map_numbers, dense_data.mol_assignments, dense_data.node_mask
-    with torch.inference_mode():
+    with torch.no_grad():          # (the reference: inference_mode; tensors made there cannot be updated outside it -- the static buffers of cached HIP graphs are)
         final_samples = model.sample_for_condition(dense_data=dense_data, n_samples=n_precursors, inpaint_node_idx=[keep],
                                                    inpaint_edge_idx=[inpaint_edge_indices] if inpaint_edge_indices else None, device=dev)
     final_samples.atom_map_numbers, final_samples.mol_assignments, final_samples.node_mask = (

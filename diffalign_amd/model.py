@@ -60,7 +60,7 @@ class DiffAlignModel(_Base):
             product_smiles = getattr(mol, 'smiles', mol)
             dense_data = inference.smiles_to_dense_data(product_smiles, cfg).to_device(self._model.device_)
             inference._ensure_transition_model(self._model, cfg, self.diffusion_steps)
-            with torch.inference_mode():
+            with torch.no_grad():          # (the reference: inference_mode; tensors made there cannot be updated outside it -- the static buffers of cached HIP graphs are)
                 final_samples = self._model.sample_for_condition(dense_data=dense_data, n_samples=n_samples, inpaint_node_idx=None,
                                                                  inpaint_edge_idx=None, device=self._model.device_)
             final_samples.atom_map_numbers, final_samples.mol_assignments, final_samples.node_mask = (
