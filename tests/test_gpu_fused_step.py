@@ -81,7 +81,8 @@ def test_fused_step_tiny_model_explicit_and_counter_noise():
         _both(model, data, z_t, t, pos, masks, chain_seeds=seeds, call=3 + t_int)
 
 
-def test_fused_step_full_widths_ragged():
+@pytest.mark.parametrize('B,n', [(5, 75), (3, 140)])
+def test_fused_step_full_widths_ragged(B, n):
     from bench import FULL, make_cfg, make_info
     from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
     from diffalign_amd.placeholder import PlaceHolder
@@ -89,7 +90,8 @@ def test_fused_step_full_widths_ragged():
     torch.manual_seed(1)
     dims = dict(FULL, n_layers=2)
     model = DiscreteDenoisingDiffusion(make_cfg(dims), make_info(), device=D).eval()
-    B, n = 5, 75                                                                        # 3 x 3 tiles, the last ones partial
+    # (5, 75): 3 x 3 tiles, the last ones partial; (3, 140): 5 tiles a row, some of them without one key whose edges are free (the last
+    # layer with last_rows computes their attention part only: da_edge_layer_ex key_free)
     true = S.make_reaction_batch(B, n, seed=4, P=None)
     data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
     pos = S.shared_pos_encodings(true, 256, seed=3).to(D)
@@ -98,6 +100,9 @@ def test_fused_step_full_widths_ragged():
     zt0 = S.noised_state(true, t=40, T=100, abs_x=S.IDX_AU, seed=9)
     z_t = data.get_new_object(X=zt0['X'].to(D), E=zt0['E'].to(D), y=zt0['y'].to(D))
     t = torch.full((B, 1), 40, dtype=torch.long, device=D)
+    if n == 140:
+        mt = torch.nn.functional.pad(masks[1].bool(), (0, 160 - n)).reshape(B, 5, 32).any(-1)
+        assert bool((~mt).any()) and bool(mt.any())
     with torch.no_grad():
         rX, rE = _both(model, data, z_t, t, pos, masks, chain_seeds=torch.arange(B, dtype=torch.int64) * 977 + 1, call=17)
         # not-free pairs keep the condition, free pairs are one-hot
