@@ -495,6 +495,9 @@ def main():
         roof['note'] = ('launches of layers >= 1 include the Etoy statistics tail (da_edge_layer_stats: early-finishing waves stream '
                         'E_in a second time, +0.74 GB and +0.06 to +0.12 ms per launch) that replaces a separate 0.155 ms pass; '
                         'DA_STATS_TAIL=0 times the bare kernel')
+    if args.workload != 'full':
+        roof['note_padding'] = ('achieved / frac count the algorithmic FLOPs of every padded pair, while the kernel leaves tiles without one real pair '
+                                'out of its attention part: on this workload frac is not a utilisation figure (the headline workload has no padding)')
     if rank == 0:
         out = {'metric': 'reverse-diffusion graph-steps/sec per node (align_absorbing)', 'value': value, 'unit': 'graph-steps/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
