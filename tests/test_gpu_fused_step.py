@@ -141,3 +141,32 @@ def test_sampling_loop_uses_the_fused_step_and_matches_the_separate_chain():
                                                     temperature=(1.0, 1.0), noise=nz(), orig=data, node_masks=masks)
             z_t.X, z_t.E = zX, zE
     assert torch.equal(got.X, z_t.X) and torch.equal(got.E, z_t.E)
+
+
+def test_last_rows_edge_cases_nothing_free_and_everything_free():
+    """Row lists at their ends: no node free (empty list: the last layer launches nothing, z_s is the condition) and every node free
+    (the list names every row: same z_s as without a list)."""
+    from diffalign_amd import graph, helpers
+    z, model, data, pos = setup()
+    B, n = data.X.shape[:2]
+    tm = model.transition_model_eval
+    t = torch.full((B, 1), 6, dtype=torch.long, device=D)
+    g = torch.Generator(device=D).manual_seed(5)
+    z_t, _ = model.apply_noise(data, t_int=t.float(), transition_model=tm,
+                               noise=(helpers.exp_noise_like((B, n, KX), D, g), helpers.exp_noise_like((B, n, n, KE), D, g)))
+    z_t.y = t.float()
+    noise = (helpers.exp_noise_like((B, n, KX), D, g), helpers.exp_noise_like((B, n, n, KE), D, g))
+    none_free = (torch.zeros(B, n, dtype=torch.bool, device=D), torch.zeros(B, n, dtype=torch.bool, device=D))
+    all_free = (data.node_mask.bool().clone(), data.node_mask.bool().clone())
+    for masks in (none_free, all_free):
+        zc = graph.apply_mask(orig=data, z_t=z_t, atom_decoder=list(ATOMS), bond_decoder=list(BONDS), node_masks=masks)
+        zc.y = t.float()
+        rows = graph.free_rows(masks)
+        assert rows.numel() == (0 if masks is none_free else int(data.node_mask.sum()))
+        ref = model.reverse_step(zc, t, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, noise=noise)
+        got = model.reverse_step(zc, t, pos_encodings=pos, transition_model=tm, orig=data, node_masks=masks, noise=noise, last_rows=rows)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        if masks is none_free:
+            real = data.node_mask.bool()
+            assert torch.equal(got[0][real], data.X.float()[real])
+            assert torch.equal(got[1][real[:, :, None] & real[:, None, :]], data.E.float()[real[:, :, None] & real[:, None, :]])
