@@ -374,7 +374,11 @@ def main():
     state['call'] = 0
     holders = [(torch.empty(B, n, kx, device=dev), data.E.float().clone()) for _ in range(2)]
     # per chain, as sample_one_batch: the last layer computes the rows of free nodes only (DA_LAST_ROWS=0: A/B switch)
-    last_rows = graph.free_rows(masks) if os.environ.get('DA_LAST_ROWS', '1') != '0' else None
+    last_rows = None
+    if os.environ.get('DA_LAST_ROWS', '1') == 'list':            # the row list alone, every tile of those rows in full
+        last_rows = graph.free_rows(masks)
+    elif os.environ.get('DA_LAST_ROWS', '1') != '0':
+        last_rows = graph.last_layers_plan(masks)
 
     def step():
         t = state['t']
@@ -449,7 +453,9 @@ def main():
     engine.PROFILE_EVENTS = None
     ev_ms = [(a.elapsed_time(b), share) for a, b, share in ev]
     edge_ms = sum(m for m, _ in ev_ms) / max(1, len(ev_ms))              # mean over ALL launches (what rocprofv3 --stats averages)
-    edge_share = sum(sh for _, sh in ev_ms) / max(1, len(ev_ms))          # mean share of the query rows a launch computes (last layer: free nodes only)
+    # mean share of a full launch's algorithmic work per launch (the last two layers of a fused step leave out what nobody reads:
+    # graph.LastLayersPlan.share_prev / share_last)
+    edge_share = sum(sh for _, sh in ev_ms) / max(1, len(ev_ms))
     full_ms = [m for m, sh in ev_ms if sh == 1.0]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -460,7 +466,7 @@ def main():
     # roofline of the dominant kernel (k_edge_layer, one launch per layer): algorithmic bytes = each 64-wide bf16 edge
     # row read once + written once; algorithmic FLOPs = 131,072 per pair
     pairs = B * n * n
-    # (the mean launch computes `edge_share` of the rows: the last layer of a fused step leaves out the rows of nodes that are not free)
+    # (the mean launch keeps `edge_share` of that: above)
     bytes_launch = pairs * 64 * 2 * 2 * edge_share
     flops_launch = pairs * 131072.0 * edge_share
     t_s = edge_ms * 1e-3
@@ -486,7 +492,7 @@ def main():
     roof = {'kernel': 'k_edge_layer<64,256,128>', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)',
             'algorithmic_bytes_per_launch': bytes_launch, 'algorithmic_flops_per_launch': flops_launch, 'avg_launch_ms': edge_ms,
-            'launches_timed': len(ev), 'mean_share_of_rows_per_launch': edge_share,
+            'launches_timed': len(ev), 'mean_share_of_full_launch_work': edge_share,
             'avg_full_launch_ms': (sum(full_ms) / len(full_ms)) if full_ms else None,
             'hbm_algorithmic_GBps': gbs, 'hbm_frac_of_8TBps': gbs / HBM_PEAK_GBS}
     if traffic_note:
@@ -510,8 +516,9 @@ def main():
                           'global_batch': B * world, 'n_nodes': n, 'parallelism': f'shard{world} (conditions x samples, no collective)',
                           'hip_graph_per_step': bool(use_graph),
                           'dead_work_elided': ('as sample_one_batch: with the product side fixed by the mask, the last layer computes the query rows of the '
-                                               'free nodes only and the fixed pairs of z_s are not rewritten -- z_s is bit-identical '
-                                               '(tests/test_gpu_fused_step.py); DA_LAST_ROWS=0 computes every row') if last_rows is not None and not use_graph else None},
+                                               'free nodes only, the last two layers form the edge features somebody reads only, and the fixed '
+                                               'pairs of z_s are not rewritten -- z_s is bit-identical (tests/test_gpu_fused_step.py); '
+                                               'DA_LAST_ROWS=0 computes everything, =list the row list alone') if last_rows is not None and not use_graph else None},
                'roofline': roof}
         if world == 1 and not args.no_loop and args.extra_features == 'inputs' and not use_graph:
             out['loop'] = loop_object(args, model, step, z_t, data, masks, dev)

@@ -104,6 +104,9 @@ struct EdgeLayerArgs {
   // positions in this list.  null: every row.  (The last layer of a fused reverse step needs only the rows of nodes that are free to
   // diffuse: nobody reads E'[i][.] or newX_in[i] of the others.)
   const int* rowmap; int n_rows;
+  // one word per query row b n + i: bit jt set = E_out[row][keys 32 jt .. 32 jt + 31] is wanted.  A tile whose bit is clear computes its
+  // attention part only (the row's newX_in needs every key): no residual, LayerNorms, FFN or store for it.  null: every tile in full
+  const unsigned* row_tiles;
   const int* n_rows_dev;  // the list's length read on the device (a launch captured in a HIP graph serves lists of any length); null: n_rows
 };
 
@@ -460,6 +463,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) kvA[e] = kvrow[((size_t)jt0 * C::NCB * 4 + e) * 64];
     uint8_t nmb = a.node_mask[b * n + min(jt0 * 32 + r, n - 1)];
+    const unsigned ktm = a.row_tiles ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.row_tiles[row]) : 0xffffffffu;
     STAMP(0)   // row setup
     for (int jt = jt0; jt < jt1; ++jt) {
       const int jl = jt * 32 + r;
@@ -587,6 +591,7 @@ __global__ void __launch_bounds__(NTHREADS) k_edge_layer(EdgeLayerArgs a) {
       }
       if (sum == 123.456f) Orow[0] = 0;
 #else
+      if (!((ktm >> jt) & 1u)) continue;                 // nobody reads E_out[row][this tile] (the next tile's rows are on their way)
       const float mean1 = xhalf_sum(sum) * (1.f / DE);
       float vs = 0.f;
 #pragma unroll
@@ -930,7 +935,8 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
                            const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                            long long split_scratch_bytes, float* stats, int stats_nchunk, int* ticket, void* stream,
                            const uint8_t* cls = nullptr, const uint8_t* in_scratch = nullptr, int de_in = 0,
-                           const int* rowmap = nullptr, int n_rows = 0, const int* n_rows_dev = nullptr) {
+                           const int* rowmap = nullptr, int n_rows = 0, const int* n_rows_dev = nullptr,
+                           const unsigned* row_tiles = nullptr) {
   DA_CHECK_ARG(B >= 0 && n >= 0, "da_edge_layer: negative size");
   DA_CHECK_ARG(E_in != E_out, "da_edge_layer: in-place not supported");
   DA_CHECK_ARG(!rowmap || (n_rows >= 0 && (long long)n_rows <= (long long)B * n), "da_edge_layer_ex: n_rows = %d outside 0 .. B n", n_rows);
@@ -949,7 +955,7 @@ static int edge_layer_impl(const void* E_in, void* E_out, const float* Q, int ld
   EdgeLayerArgs a{(const bf16_t*)E_in, (bf16_t*)E_out, Q, ldq, (const uint4*)KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1,
                   newX_in, (const uint4*)blob, qscale, B, n, split, max_rem * NT, 0, 0, 0, 0, 1, stats, stats_nchunk, ticket,
                   cls, cls ? reinterpret_cast<const uint4*>(in_scratch + in_table_offset(B)) : nullptr, in_scratch, de_in + 2,
-                  rowmap, n_rows, rowmap ? n_rows_dev : nullptr};
+                  rowmap, n_rows, n <= 1024 ? row_tiles : nullptr, rowmap ? n_rows_dev : nullptr};
   { const EdgeTuning tune = edge_tuning();
     a.stagger = tune.stagger; a.prio = tune.prio; a.skip_dead = tune.skip_dead;
     // default skew: ~60 % of a SIMD pair's rows to the older wave (measured optimum at 9 rows per wave: 11 / 7, -3 % per launch)
@@ -1021,18 +1027,21 @@ int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, 
 //   of newX_in (both stay as they were); the split scratch is sized by da_edge_split_scratch_bytes_rows(n_rows, n, dx).
 //   n_rows_dev (optional): the list's length as an int in device memory, read by the kernels -- n_rows is then the caller's estimate
 //   (grid and shares are chosen for it) and the scratch is sized by da_edge_split_scratch_bytes_rows(-n_rows, n, dx) (any length).
+//   row_tiles (optional, B n words, n <= 1024; ignored beyond): bit jt of word b n + i set = E_out[b][i][32 jt .. 32 jt + 31] is wanted.
+//   Tiles whose bit is clear take part in the row's attention (newX_in is complete) but their E_out entries stay as they were.
 int da_edge_layer_ex(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                      const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                      const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                      long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, const uint8_t* cls_map,
-                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, const int* n_rows_dev, void* stream) {
+                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, const int* n_rows_dev, const unsigned* row_tiles,
+                     void* stream) {
   DA_CHECK_ARG((stats_partials == nullptr) == (ticket == nullptr) && (stats_partials == nullptr || stats_nchunk >= 1),
                "da_edge_layer_ex: statistics partials and ticket go together");
   DA_CHECK_ARG((cls_map == nullptr) == (in_scratch == nullptr) && (cls_map == nullptr || (de_in >= 1 && de_in <= 8)),
                "da_edge_layer_ex: class map and input scratch go together (1 <= de_in <= 8)");
   return edge_layer_impl(E_in, E_out, Q, ldq, KV_frag, node_mask, ye2p1, ebias, yx1, yx2p1, newX_in, blob, qscale, B, n, de, dx, dff,
                          split_scratch, split_scratch_bytes, stats_partials, stats_nchunk, ticket, stream, cls_map, in_scratch, de_in,
-                         rowmap, n_rows, n_rows_dev);
+                         rowmap, n_rows, n_rows_dev, row_tiles);
 }
 
 }  // extern "C"

@@ -148,9 +148,10 @@ class DiscreteDenoisingDiffusion(SamplingMixin, ELBOMixin, TrainingMixin, nn.Mod
         `out` = (X, E): preallocated fp32 tensors that receive z_s (and are returned); they must not be z_t's.
         `out_holds_condition`: the caller's promise that out's E already has the condition's values (`orig`) at every pair that is not
         free to diffuse -- true for a buffer that held an earlier state of the same chain: those pairs are then not written again.
-        `last_rows`: graph.free_rows(node_masks, node_mask) of this chain (computed once per chain: one host sync): the denoiser's last
-        layer then computes the query rows of free nodes only -- nothing else of it is read by the fused step (pred.X is then defined on
-        those rows only)."""
+        `last_rows`: graph.last_layers_plan(node_masks) of this chain (computed once per chain: host syncs), or graph.free_rows' list
+        alone: the denoiser's last layer then computes the query rows of free nodes only -- nothing else of it is read by the fused
+        step (pred.X is then defined on those rows only) --, and with a plan the last two layers form the edge features of the pairs
+        somebody reads only (graph.LastLayersPlan)."""
         from . import helpers
         tm = transition_model if transition_model is not None else self.transition_model_eval
         if tables is not None:       # (Q_t, Qbar_{t-1}, Qbar_t) of this step laid out by the caller (graphs.GraphedChain)

@@ -59,7 +59,7 @@ def use_stats_tail(n: int) -> bool:
 CAPTURE_SIDE_STREAMS = True   # under HIP-graph capture the side streams join the capture through their events (False: one stream)
 TABLE_IN = True        # first edge layer reads its input rows from the input stage's table (da_edge_in_classes / da_edge_layer_table)
 SPLIT_TAIL = True      # load-balance the edge kernel's last round (da_edge_split_scratch_bytes); False: whole rows only
-PROFILE_EVENTS = None   # bench.py sets this to a list: (start event, end event, share of the query rows computed) per da_edge_layer launch
+PROFILE_EVENTS = None   # bench.py sets this to a list: (start event, end event, share of a full launch's algorithmic work) per da_edge_layer launch
 
 
 def _i(v):
@@ -201,11 +201,13 @@ def _qkv_buffers(pm: PackedModel, B, n, dev):
     return torch.empty(B * n, pm.dx if pm.fused_qkv else 3 * pm.dx, device=dev), kvf
 
 
-def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None, rows=None):
+def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None, rows=None, row_tiles=None, share=None):
     """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out.
     `table` = (cls_map, scratch) of da_edge_in_classes: the first layer reads its input rows from the input stage's table.
     `rows`: int32 tensor of the query rows b n + i to compute, ascending (da_edge_layer_ex): the others get zeros in newX_in and
-    nothing in E' (the last layer of a fused reverse step: only the rows of nodes that are free to diffuse are read again)."""
+    nothing in E' (the last layer of a fused reverse step: only the rows of nodes that are free to diffuse are read again).
+    `row_tiles`: (B n,) int32, bit jt of a row's word set = E'[row][keys 32 jt ..] is wanted (graph.LastLayersPlan); the other tiles
+    compute their attention part only.  `share`: the launch's share of a full launch's algorithmic FLOPs, for PROFILE_EVENTS."""
     dev, dx, de, lib, S = E_bf16.device, pm.dx, pm.de, L.lib(), L.stream()
     ye2p1, ebias, yx1, yx2p1 = film
     E_out = torch.empty_like(E_bf16)
@@ -226,11 +228,13 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
             L.ptr(ebias), L.ptr(yx1), L.ptr(yx2p1), L.ptr(newX_in), L.ptr(lw['blob']),
             C.c_float(1.0 / math.sqrt(dx // pm.n_head)), _i(B), _i(n), _i(de), _i(dx), _i(pm.dffe),
             L.ptr(split), C.c_longlong(split.numel() if split is not None else 0))
-    if rows is not None:
-        assert table is None and rows.dtype == torch.int32 and rows.is_contiguous()
+    if rows is not None or row_tiles is not None:
+        assert table is None and (rows is None or (rows.dtype == torch.int32 and rows.is_contiguous()))
+        assert row_tiles is None or (row_tiles.dtype == torch.int32 and row_tiles.is_contiguous() and row_tiles.numel() == B * n)
         N_ = L.ptr(None)
         L.check(lib.da_edge_layer_ex(*args, L.ptr(stats_out), _i(stats_out.shape[1] if stats_out is not None else 0), L.ptr(ticket),
-                                     N_, N_, _i(0), L.ptr(rows), _i(n_rows), L.ptr(rows_dev), S), 'da_edge_layer_ex')
+                                     N_, N_, _i(0), L.ptr(rows), _i(n_rows if rows is not None else 0), L.ptr(rows_dev), L.ptr(row_tiles), S),
+                'da_edge_layer_ex')
     elif table is not None:
         assert stats_out is None
         L.check(lib.da_edge_layer_table(*args, L.ptr(table[0]), L.ptr(table[1]), _i(pm.de_in), S), 'da_edge_layer_table')
@@ -239,7 +243,7 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
     else:
         L.check(lib.da_edge_layer(*args, S), 'da_edge_layer')
     if profile:
-        ev1.record(); PROFILE_EVENTS.append((ev0, ev1, n_rows / float(B * n)))
+        ev1.record(); PROFILE_EVENTS.append((ev0, ev1, float(share) if share is not None else n_rows / float(B * n)))
     return E_out, newX_in, split
 
 
@@ -350,6 +354,16 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+def _last_plan(last_rows):
+    """reverse_step's last_rows (graph.free_rows' tensor, (list, length on the device, estimate), or a graph.LastLayersPlan) as a plan."""
+    from .graph import LastLayersPlan
+    if last_rows is None or isinstance(last_rows, LastLayersPlan):
+        return last_rows
+    if isinstance(last_rows, tuple):
+        return LastLayersPlan(last_rows[0], last_rows[1], last_rows[2])
+    return LastLayersPlan(last_rows)
+
+
 def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B, n, main, side, side2, pre, table0=None, last_rows=None):
     """The layer stack with the NODE chain on the caller's stream (merge, node tail of layer l, q/k/v of layer l+1 directly behind the
     edge kernel and in front of the next one: no cross-stream event on it) and the y chain on the side stream (edge kernel -> event ->
@@ -362,6 +376,7 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
     `pre` = (Qm, kvf, xst, xy) of layer 0 from the input stage (model_forward)."""
     dev = Xh.device
     Qm, kvf, xst, xy = pre
+    plan = _last_plan(last_rows)
     if y_done0 is not None:
         main.wait_event(y_done0)                     # FiLM vectors of layer 0 (y stream of the input stage)
     xs_done = None                                   # Xtoy term of the coming layer complete (third stream)
@@ -371,7 +386,10 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
         nxt = pm.layers[li + 1] if li + 1 < len(pm.layers) else None
         # the last layer of a fused reverse step with a row list: its y output is read by nobody (the step returns z_s), so neither the
         # Etoy statistics of its input (the edge kernel's tail) nor its y update are computed; the stream joins stay as they are
-        no_y = nxt is None and li > 0 and last_rows is not None
+        no_y = nxt is None and li > 0 and plan is not None
+        # the layer before it: its E' is the last layer's input, which reads the rows of the list only -- the other rows compute their
+        # attention part (their node features are every row's keys in the last layer) and form no E'; nobody reads that E's statistics
+        pre_last = plan is not None and li > 0 and li + 2 == len(pm.layers)
         tail = tail_stats_buffer(pm, B, n, dev) if li > 0 and use_stats_tail(n) and not no_y else None
         st = st0 if li == 0 else (tail if tail is not None else st_pass)
         st_next = (torch.empty(B, stat_chunks(n), 4, pm.de, dtype=torch.float32, device=dev)
@@ -382,8 +400,15 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
         qkv_next = _qkv_buffers(pm, B, n, dev) if nxt is not None else None
         xst_next = torch.empty(B, N_XSTAT_CHUNKS, 4, pm.dx, device=dev) if nxt is not None else None
         xy_next = torch.empty(B, pm.dy, device=dev) if nxt is not None else None
-        E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None,
-                                       rows=last_rows if nxt is None and li > 0 else None)
+        if no_y:
+            rows_arg = (plan.rows, plan.n_rows_dev, plan.hint) if plan.n_rows_dev is not None else plan.rows
+            E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, rows=rows_arg, row_tiles=plan.tiles_last,
+                                           share=plan.share_last if plan.tiles_last is not None else None)
+        elif pre_last and plan.tiles_prev is not None:
+            E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, row_tiles=plan.tiles_prev,
+                                           share=plan.share_prev if plan.share_prev is not None else 1.0)
+        else:
+            E_next, newX_in, split = _edge(pm, lw, Eh, Qm, kvf, nm, film, B, n, tail, table=table0 if li == 0 else None)
         ev_edge = main.record_event()
         with torch.cuda.stream(side):                # y chain
             side.wait_event(ev_edge)
@@ -391,7 +416,7 @@ def _layers_node_on_main(pm: PackedModel, Xh, Eh, yh, nm, st0, film, y_done0, B,
                 side.wait_event(xs_done)             # xy of this layer (recorded one edge kernel ago)
             if not no_y:
                 y_update_film(pm, lw, nxt, yh, xy, st, B, n, y_next, film_next)
-            if st_next is not None:
+            if st_next is not None and not pre_last:
                 edge_stats(E_next, B, n, pm.de, out=st_next)
             ev_y = side.record_event()
         _x_post(pm, lw, newX_in, Xh, nm, B, n, out=X_next)

@@ -73,6 +73,51 @@ def free_rows(node_masks) -> torch.Tensor:
     return torch.nonzero(need.reshape(-1)).squeeze(1).to(torch.int32).contiguous()
 
 
+class LastLayersPlan:
+    """What the last two layers of a fused reverse step compute (DiscreteDenoisingDiffusion.reverse_step last_rows=): the step reads the
+    node logits of free nodes and the edge logits of pairs with both ends free, nothing else of the denoiser's output.
+    rows / n_rows_dev / hint: the last layer's query rows (free_rows), optionally with the list's length in device memory and an estimate
+    tiles_last: per query row b n + i, bit jt set = the last layer's E'[i][keys 32 jt ..] is wanted (i free for E and a key of that tile too)
+    tiles_prev: the same for the layer before: its E' is the last layer's input, read for the rows of the list only
+    share_last / share_prev: share of a full launch's algorithmic FLOPs those launches keep (bench.py's roofline; None: not computed)"""
+    __slots__ = ('rows', 'n_rows_dev', 'hint', 'tiles_prev', 'tiles_last', 'share_prev', 'share_last')
+
+    def __init__(self, rows, n_rows_dev=None, hint=None, tiles_prev=None, tiles_last=None, share_prev=None, share_last=None):
+        self.rows, self.n_rows_dev, self.hint = rows, n_rows_dev, (int(rows.numel()) if hint is None else int(hint))
+        self.tiles_prev, self.tiles_last, self.share_prev, self.share_last = tiles_prev, tiles_last, share_prev, share_last
+
+
+def row_tile_masks(node_masks) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(tiles_prev, tiles_last) of LastLayersPlan for get_node_masks' pair: two (B n,) int32 tensors (no host sync).  n <= 1024."""
+    mx, me = node_masks[0].bool(), node_masks[1].bool()
+    B, n = me.shape
+    nt = (n + 31) // 32
+    assert nt <= 32, 'row tile masks: n <= 1024'
+    key_tiles = torch.nn.functional.pad(me, (0, nt * 32 - n)).reshape(B, nt, 32).any(-1)                 # (B, nt): tile has a key free for E
+    bits = (key_tiles.long() << torch.arange(nt, device=me.device)).sum(-1)                            # (B,)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits)                                           # as the int32 bit pattern
+    tiles_last = torch.where(me, bits[:, None], torch.zeros_like(bits[:, None])).to(torch.int32).reshape(-1).contiguous()
+    tiles_prev = torch.where(mx | me, -1, 0).to(torch.int32).reshape(-1).contiguous()
+    return tiles_prev, tiles_last
+
+
+def last_layers_plan(node_masks) -> LastLayersPlan:
+    """LastLayersPlan of a chain from get_node_masks' pair: once per chain (host syncs for the list's length and the FLOP shares)."""
+    mx, me = node_masks[0].bool(), node_masks[1].bool()
+    B, n = me.shape
+    rows = free_rows(node_masks)
+    if n > 1024:
+        return LastLayersPlan(rows)
+    tiles_prev, tiles_last = row_tile_masks(node_masks)
+    nt = (n + 31) // 32
+    need = (mx | me).float()
+    # algorithmic FLOPs per pair: the attention part (e_mul / e_add projection) is half, e_out + the feed-forward block the other half
+    kt = torch.nn.functional.pad(me, (0, nt * 32 - n)).reshape(B, nt, 32).any(-1).float().sum(-1) / nt        # wanted key tiles per graph
+    share_prev = float((need + (1 - need) * 0.5).mean())
+    share_last = float((need * 0.5 + me.float() * 0.5 * kt[:, None]).mean())
+    return LastLayersPlan(rows, None, None, tiles_prev, tiles_last, share_prev, share_last)
+
+
 def from_mask_to_maskX_maskE(mask_nodes, mask_edges, shape_X, shape_E):
     """graph.py:607-619 (expanded views, built only when a caller asks for the dense masks)."""
     mask_X = mask_nodes.unsqueeze(-1).expand(-1, -1, shape_X[-1])

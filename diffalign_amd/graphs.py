@@ -188,6 +188,9 @@ class GraphedChain:
         self.rows = torch.zeros(B * n, dtype=torch.int32, device=dev)
         self.n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rows_hint = None
+        # per-row tile masks of the last two layers (graph.row_tile_masks), static like the list
+        self.tiles_prev = torch.zeros(B * n, dtype=torch.int32, device=dev) if n <= 1024 else None
+        self.tiles_last = torch.zeros(B * n, dtype=torch.int32, device=dev) if n <= 1024 else None
         self.eig = None
         if with_eig_cache:                                   # sized for any fixed block of this shape; filled per chain by load()
             self.eig = EigCache(torch.zeros(B, dtype=torch.int32, device=dev), n)
@@ -216,6 +219,9 @@ class GraphedChain:
         self.n_rows.fill_(int(rows.numel()))
         if self.rows_hint is None:
             self.rows_hint = int(rows.numel())
+        if self.tiles_prev is not None:
+            tp, tl = graph.row_tile_masks(masks)
+            self.tiles_prev.copy_(tp); self.tiles_last.copy_(tl)
         if pad_noise is not None:                            # drawn per chain only when the extra features' eigensolver runs
             self.pad_noise.copy_(pad_noise)
         ts = self.T_eval if t_start is None else int(t_start)
@@ -245,7 +251,7 @@ class GraphedChain:
         m.reverse_step(z, self.all_t[t], pos_encodings=self.pos, transition_model=m.transition_model_eval, temperature=self.temps,
                        orig=self.data, node_masks=self.masks, t_int=t, chain_seeds=self.seeds,
                        call=self.first_call + (self.T_eval - t), tables=self._tables(t), out=(zo.X, zo.E), out_holds_condition=True,
-                       last_rows=(self.rows, self.n_rows, self.rows_hint) if self.rows_hint else None)
+                       last_rows=graph.LastLayersPlan(self.rows, self.n_rows, self.rows_hint, self.tiles_prev, self.tiles_last) if self.rows_hint else None)
         graph.apply_inpainting(zo, self.data, self.fix_nodes, self.fix_edges)
         if not m.cfg.diffusion.diffuse_edges:
             zo.E.copy_(self.data.E)

@@ -121,7 +121,7 @@ class SamplingMixin:
                     holders = [(torch.empty(B, n, dense_data.X.shape[-1], device=device), dense_data.E.float().clone()) for _ in range(2)]
                 out = holders[1] if z_t.E.data_ptr() == holders[0][1].data_ptr() else holders[0]
                 if last_rows is None:                                      # (one host sync per chain)
-                    last_rows = graph.free_rows(masks)
+                    last_rows = graph.last_layers_plan(masks)
                 zsX, zsE, _ = self.reverse_step(z_t, t_array, pos_encodings=pos_encodings, transition_model=tm, temperature=temps,
                                                 orig=dense_data, node_masks=masks, t_int=t_int, out=out, out_holds_condition=True,
                                                 last_rows=last_rows, **nz(step=True))

@@ -350,13 +350,18 @@ int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, 
  * value whatever its logits are, so only the rows of free nodes are ever read again.  The split scratch is then sized by
  * da_edge_split_scratch_bytes_rows(n_rows, n, dx).  n_rows_dev (optional): the list's length as an int32 in device memory, read by
  * the kernels, so that a launch captured in a HIP graph serves lists of any length; n_rows is then the caller's estimate (grid and
- * shares are chosen for it) and the scratch is sized by da_edge_split_scratch_bytes_rows(-n_rows, n, dx). */
+ * shares are chosen for it) and the scratch is sized by da_edge_split_scratch_bytes_rows(-n_rows, n, dx).
+ * row_tiles (optional; B n words, used for n <= 1024): bit jt of word b n + i set = E_out[b][i][32 jt .. 32 jt + 31] is wanted; a tile
+ * whose bit is clear takes part in the row's attention (newX_in is complete) and its E_out entries stay as they were.  For the last
+ * two layers of a fused reverse step: the last reads E[i][.] of free rows only, so the one before forms no E_out for the other rows,
+ * and of the last layer's E_out the output stage reads the pairs with both ends free. */
 long long da_edge_split_scratch_bytes_rows(long long rows, int n, int dx);
 int da_edge_layer_ex(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                      const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                      const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
                      long long split_scratch_bytes, float* stats_partials, int stats_nchunk, int* ticket, const uint8_t* cls_map,
-                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, const int* n_rows_dev, void* stream);
+                     const uint8_t* in_scratch, int de_in, const int* rowmap, int n_rows, const int* n_rows_dev, const unsigned* row_tiles,
+                     void* stream);
 /* Launch tuning of da_edge_layer / da_edge_layer_stats, process-wide (no counterpart in the reference; for tests and A/B timing):
  * threads per workgroup 256 | 512 (0 = keep), skew = whole rows the older wave of every SIMD pair takes more than the younger one,
  * tail_old = the split rows' runs go to the older waves only (both: -1 = chosen from the problem size), stagger, prio = start

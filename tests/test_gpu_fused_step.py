@@ -59,6 +59,17 @@ def _both(model, data, z_t, t, pos, masks, **noise_kw):
     need = (masks[0].bool() | masks[1].bool())
     assert torch.equal(pred4.X[need], pred.X[need]) and bool(torch.isfinite(pred4.X).all())
     assert pred4.E is None and (pred4.y is None or len(model.model.tf_layers) == 1)       # the last layer's y is not computed either
+    # a plan (graph.last_layers_plan): besides the row list, the last two layers form E' only where somebody reads it (per-row tile
+    # masks of da_edge_layer_ex): the same z_s and the same node logits again, eager and with the list's length on the device
+    plan = G.last_layers_plan(masks)
+    assert torch.equal(plan.rows, rows) and 0 < plan.share_last < plan.share_prev <= 1
+    n_dev = torch.tensor([rows.numel()], dtype=torch.int32, device=rows.device)
+    buf = torch.zeros(B * n, dtype=torch.int32, device=rows.device); buf[:rows.numel()] = rows
+    for pl in (plan, G.LastLayersPlan(buf, n_dev, rows.numel(), plan.tiles_prev, plan.tiles_last)):
+        zsX5, zsE5, pred5 = model.reverse_step(z_t, t, pos_encodings=pos, transition_model=tm, temperature=(1.0, 0.9), orig=data, node_masks=masks,
+                                               last_rows=pl, **noise_kw)
+        assert torch.equal(zsX5, rX) and torch.equal(zsE5, rE)
+        assert torch.equal(pred5.X[need], pred.X[need]) and bool(torch.isfinite(pred5.X).all())
     return rX, rE
 
 
@@ -88,7 +99,7 @@ def test_fused_step_full_widths_ragged(B, n):
     from diffalign_amd.placeholder import PlaceHolder
     from diffalign_amd import graph, synthetic as S
     torch.manual_seed(1)
-    dims = dict(FULL, n_layers=2)
+    dims = dict(FULL, n_layers=3)                                                       # layer 1 is the layer before the last
     model = DiscreteDenoisingDiffusion(make_cfg(dims), make_info(), device=D).eval()
     # (5, 75): 3 x 3 tiles, the last ones partial; (3, 140): 5 tiles a row, some of them without one key whose edges are free (the last
     # layer with last_rows computes their attention part only: da_edge_layer_ex key_free)
