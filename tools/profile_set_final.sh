@@ -24,5 +24,5 @@ timeout -k 10 300 python bench.py --workload train --steps 10 --warmup 3 > $O/tr
 bash tools/prof_train.sh final > $O/prof_train.txt 2>&1 || exit 1
 cp $(find gpurun_out/prof_train_final -name '*kernel_stats.csv' | sort | tail -1) $O/train_kernel_stats.csv
 for f in bench_line bench_line_profiled bench_line_n72 bench_line_n140 bench_line_uspto_like bench_line_device_features train_line; do
-  python -c "import json,sys; d=json.load(open('$O/$f.json')); print('$f', round(d['ms_per_step'],3), (d.get('roofline') or {}).get('frac'), (d.get('roofline') or {}).get('traffic'))"
+  python -c "import json,sys; d=json.load(open('$O/$f.json')); r=d.get('roofline'); r=r if isinstance(r,dict) else {}; print('$f', round(d['ms_per_step'],3), r.get('frac'), r.get('traffic'))"
 done
