@@ -458,6 +458,12 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
     nm = L.as_u8(node_mask)
     main, sides = torch.cuda.current_stream(), _side_stream(dev)
     side, side2 = sides if sides is not None else (None, None)
+    # X / y columns still being written on another stream (compute_extra_data: the eigensolver's features): (event, tensors to hold until
+    # this stream has waited).  The node and y input paths wait for it on their streams; this stream enqueues the edge input stage,
+    # which reads only E, first.
+    pending = step.pop('inputs_ready', None) if step is not None else None
+    if pending is not None and (side is None or side2 is None):
+        main.wait_event(pending[0]); pending = None
     # ---- input stage.  The node path (two linears, positional encodings, the alignment index of the skip connection) depends
     # on the inputs only: with side streams it runs beside the edge input stage.
     h0 = torch.empty(R, pm.hx, device=dev)
@@ -500,6 +506,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         in_ready = main.record_event()
         with torch.cuda.stream(side2):
             side2.wait_event(in_ready)
+            if pending is not None:
+                side2.wait_event(pending[0])
             node_features()
             xin_done = side2.record_event()
             alignment()
@@ -518,6 +526,8 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                                                      # BEFORE that stage (behind it in program order the two kernels also ran behind it)
         with torch.cuda.stream(side):
             side.wait_event(in_ready)
+            if pending is not None:
+                side.wait_event(pending[0])
             y_input_path()
             layer_film(pm, pm.layers[0], yh, B, film0)
             y_done0 = side.record_event()
@@ -536,6 +546,9 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                                    _i(pm.he), S), 'da_edge_in_sym')
     # ---- layers
     st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
+    if pending is not None:
+        main.wait_event(pending[0])                  # (its tensors were allocated on this stream: held until here)
+        pending = None
     if xin_done is not None:
         main.wait_event(xin_done)
     if side is None:

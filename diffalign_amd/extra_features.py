@@ -219,12 +219,16 @@ def _eigen_into(Lap, nm_u8, pad_noise, Xf, x_col, yf, y_col, cache: Optional[Eig
 
 def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: ExtraMolecularFeatures,
                            pad_noise: Optional[torch.Tensor] = None, eig_cache: Optional[EigCache] = None,
-                           base: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           base: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, defer_join: bool = False):
     """The two calculators of diffusion_abstract.py:350-372 with ONE pass over the edge state.
     Returns (X_extra (B,n,8), y_extra (B,12)) in the reference's concatenation order (features_type 'all'), or, with
     base = (X0, y0), the denoiser's widened inputs (cat(X0, X_extra), cat(y0, y_extra)) of :366-371.  The rows are assembled in
     place: everything but the six eigen-features sits in its columns while the eigensolver still runs, and the solver writes
-    those itself -- behind it, on the step's critical path, nothing is left (seven small torch launches before)."""
+    those itself -- behind it, on the step's critical path, nothing is left (seven small torch launches before).
+    `defer_join`: return (Xf, yf, pending) without making the caller's stream wait for the eigensolver's stream; pending = (event,
+    tensors the solver still uses) or None.  Whoever reads Xf / yf waits for the event on its stream, and the CALLER'S stream must wait
+    for it too before `pending` is dropped (the tensors were allocated on it): engine.model_forward(step['inputs_ready']) does both,
+    with the edge input stage -- which reads none of this -- enqueued in front of the wait."""
     assert extra.features_type == 'all'
     dev = E.device
     B, n = node_mask.shape
@@ -260,5 +264,7 @@ def compute_extra_features(X, E, node_mask, extra: ExtraFeatures, molecular: Ext
             _eigen_into(Lap, nm_u8, pad_noise, Xf, kx0 + 3, yf, ky0 + 5, eig_cache)
             done = side.record_event()
         rest()
+        if defer_join:
+            return Xf, yf, (done, (Lap, A, nm_u8, pad_noise, Xf, yf))
         main.wait_event(done)       # (Xf, yf, Lap, pad_noise: allocated on the caller's stream, which has now waited for their last use)
-    return Xf, yf
+    return (Xf, yf, None) if defer_join else (Xf, yf)

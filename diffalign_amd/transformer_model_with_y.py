@@ -90,12 +90,21 @@ class GraphTransformerWithY(_DenoiserBase):
     def forward(self, X, E, y, node_mask, step=None):
         self._check(X)
         if self._unfused():
+            _join_inputs(step)
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask, precision=self._unfused_precision()) + (node_mask,)
         pm = self._pack(X.device)
         Xo, Eo, yh = engine.model_forward(pm, X, E, y, node_mask, step=step)
         yo = None if yh is None else yh[..., :self.out_dim_y] + y[..., :self.out_dim_y]    # (None: fused step with a row list)
         return Xo, Eo, yo, node_mask
+
+
+def _join_inputs(step):
+    """The caller's stream waits for inputs still being written on another one (compute_extra_data: the eigensolver's columns of X
+    and y) -- for the paths that read X or y before engine.model_forward, which otherwise places that wait itself."""
+    pending = step.pop('inputs_ready', None) if step is not None else None
+    if pending is not None:
+        torch.cuda.current_stream().wait_event(pending[0])
 
 
 class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
@@ -122,6 +131,8 @@ class GraphTransformerWithYAtomMapPosEmb(_DenoiserBase):
     def forward(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments, step=None):
         assert atom_map_numbers is not None
         self._check(X)
+        if self._unfused() or self.input_alignment:
+            _join_inputs(step)
         if self._unfused():
             from .train_forward import forward_train
             return forward_train(self, X, E, y, node_mask, atom_map_numbers, pos_encodings, mol_assignments,
