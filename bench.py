@@ -326,14 +326,26 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist_
         dist = dist_
-        if 'MASTER_ADDR' in os.environ and 'RANK' in os.environ:
-            dist.init_process_group('nccl', device_id=dev)
-        else:                                                  # --force-dist outside a launcher: a group of this one process
-            import socket
-            with socket.socket() as sk:
-                sk.bind(('127.0.0.1', 0))
-                port = sk.getsockname()[1]
-            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+        # RCCL writes its version banner to stdout when the communicator is created (at init with device_id, or at the first collective):
+        # both happen here with stdout pointing at stderr, so that the JSON line stays the only thing this program writes to stdout
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if 'MASTER_ADDR' in os.environ and 'RANK' in os.environ:
+                dist.init_process_group('nccl', device_id=dev)
+            else:                                              # --force-dist outside a launcher: a group of this one process
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    port = sk.getsockname()[1]
+                dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
 
     from diffalign_amd.diffusion_abstract import DiscreteDenoisingDiffusion
     from diffalign_amd.placeholder import PlaceHolder
