@@ -204,7 +204,7 @@ def _qkv_buffers(pm: PackedModel, B, n, dev):
 def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_out=None, table=None, rows=None, row_tiles=None, share=None):
     """The fused edge layer (+ the merge of its split rows): E' (bf16) and the attention output newX_in (R, dx) before x_out.
     `table` = (cls_map, scratch) of da_edge_in_classes: the first layer reads its input rows from the input stage's table.
-    `rows`: int32 tensor of the query rows b n + i to compute, ascending (da_edge_layer_ex): the others get zeros in newX_in and
+    `rows`: int32 tensor of the query rows b n + i to compute, ascending (da_edge_layer_ex): the others keep what a per-size buffer holds in newX_in (zeros or earlier outputs: finite) and
     nothing in E' (the last layer of a fused reverse step: only the rows of nodes that are free to diffuse are read again).
     `row_tiles`: (B n,) int32, bit jt of a row's word set = E'[row][keys 32 jt ..] is wanted (graph.LastLayersPlan); the other tiles
     compute their attention part only.  `share`: the launch's share of a full launch's algorithmic FLOPs, for PROFILE_EVENTS."""
@@ -219,7 +219,16 @@ def _edge(pm: PackedModel, lw: dict, E_bf16, Qm, kvf, nm_u8, film, B, n, stats_o
         n_rows = int(rows.numel()) if rows is not None else B * n
     nsplit = lib.da_edge_split_scratch_bytes_rows(C.c_longlong(-n_rows if rows_dev is not None else n_rows), _i(n), _i(dx)) if SPLIT_TAIL else 0
     split = torch.empty(nsplit, dtype=torch.uint8, device=dev) if nsplit > 0 else None
-    newX_in = torch.empty(B * n, dx, device=dev) if rows is None else torch.zeros(B * n, dx, device=dev)
+    if rows is None:
+        newX_in = torch.empty(B * n, dx, device=dev)
+    else:
+        # the rows left out keep what the buffer holds, and the node tail reads every row: one buffer per size that starts as zeros and
+        # only ever receives attention outputs (finite), instead of a fill launch in front of the step's last edge kernel.  Calls on
+        # one stream are ordered; two streams driving the same packed model at once would share it.
+        cache = pm.__dict__.setdefault('_rowlist_newx', {})
+        newX_in = cache.get((B * n, dx))
+        if newX_in is None or newX_in.device != dev:
+            newX_in = cache[(B * n, dx)] = torch.zeros(B * n, dx, device=dev)
     ticket = pm.ticket if stats_out is not None else None
     profile = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
     if profile:
