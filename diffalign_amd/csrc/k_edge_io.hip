@@ -135,10 +135,14 @@ __global__ void __launch_bounds__(256) k_edge_in(const float* __restrict__ E_in,
 // k_edge_in_tiles then writes E_h[b,i,j,:] = T[class(b,i,j)] with coalesced 16-byte stores: 28 B read + 2 DE B written
 // per pair and no arithmetic.
 template <int DE, int HE>
-__global__ void __launch_bounds__(64) k_edge_in_table(int de_in, const uint4* __restrict__ blob, uint4* __restrict__ T) {
+__global__ void __launch_bounds__(64) k_edge_in_table(int de_in, const uint4* __restrict__ blob, uint4* __restrict__ T,
+                                                      uint8_t* __restrict__ flags, int n_flags, int* __restrict__ hist, int n_hist) {
   using C = EdgeIoCfg<DE, HE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* sW = reinterpret_cast<uint4*>(smem);
+  // the stage's flags start as set and its class counts as zero (two fill launches before): k_edge_in_tiles runs behind this kernel
+  for (int t = threadIdx.x; t < n_flags; t += 64) flags[t] = 1;
+  for (int t = threadIdx.x; t < n_hist; t += 64) hist[t] = 0;
   for (int t = threadIdx.x; t < (int)(C::IN_BYTES / 16); t += 64) sW[t] = blob[t];
   float* sI = reinterpret_cast<float*>(smem + C::IN_BYTES);       // [32][de_in]: row r = one-hot(r) (zero for r >= de_in)
   for (int t = threadIdx.x; t < 32 * de_in; t += 64) sI[t] = (t / de_in == t % de_in) ? 1.f : 0.f;
@@ -718,13 +722,12 @@ static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void
                      uint8_t* sym_flags = nullptr, uint8_t* cls_map = nullptr) {
   using C = EdgeIoCfg<DE, HE>;
   if (sym_flags) {                                    // scratch: [B] symmetric, [B] one-hot, 16-byte aligned table
-    if (hipMemsetAsync(sym_flags, 1, 2 * (size_t)B, s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     const int nt = (n + 31) / 32;
     uint4* T = reinterpret_cast<uint4*>(sym_flags + in_table_offset(B));
     int* hist = reinterpret_cast<int*>(sym_flags + in_hist_offset(B, de_in, DE));
-    if (hipMemsetAsync(hist, 0, (size_t)B * IN_HIST * sizeof(int), s) != hipSuccess) { da_set_error("da_edge_in_sym: memset failed"); return DA_ERR_HIP; }
     if (de_in <= 8) {
-      k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T);
+      k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T, sym_flags, 2 * B, hist,
+                                                                                      B * IN_HIST);
       const dim3 grid(nt * (nt + 1) / 2, B);
       const size_t lds = 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float);
       if (cls_map) k_edge_in_tiles<DE, true><<<grid, 256, lds, s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist, cls_map);
