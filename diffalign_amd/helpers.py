@@ -102,8 +102,20 @@ def reverse_step_ctx(z_t: PlaceHolder, Qt: PlaceHolder, Qsb: PlaceHolder, Qtb: P
             call = 0
         seeds = chain_seeds.to(device=dev, dtype=torch.int64).contiguous()
         qX = torch.empty(B, n, kx, device=dev)
-        L.check(L.lib().da_counter_exp_noise(L.ptr(seeds, torch.int64), int(call), L.ptr(qX), L.ptr(None), B, n, kx, ke, L.stream()),
-                'da_counter_exp_noise')
+        # the node half's noise is read at the END of the step (da_posterior_sample behind the node output path): generated on the y
+        # stream, beside the input stage, instead of in front of it (the caller's stream joins that stream before the first layer)
+        from . import engine
+        sides = engine._side_stream(dev)
+        if sides is not None and not torch.cuda.is_current_stream_capturing():   # (captured steps keep it on the caller's stream: a
+            # fork this early in the captured step made the graph's replay fault)
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(sides[0]):
+                sides[0].wait_event(ev)
+                L.check(L.lib().da_counter_exp_noise(L.ptr(seeds, torch.int64), int(call), L.ptr(qX), L.ptr(None), B, n, kx, ke, L.stream()),
+                        'da_counter_exp_noise')
+        else:
+            L.check(L.lib().da_counter_exp_noise(L.ptr(seeds, torch.int64), int(call), L.ptr(qX), L.ptr(None), B, n, kx, ke, L.stream()),
+                    'da_counter_exp_noise')
     if out is not None:          # the caller's buffers receive z_s (graphs.GraphedChain: the chain's state alternates between two holders)
         zsX, zsE = out
         assert zsX.shape == (B, n, kx) and zsE.shape == (B, n, n, ke) and zsX.dtype == zsE.dtype == torch.float32
