@@ -102,7 +102,7 @@ def test_fused_step_full_widths_ragged(B, n):
     dims = dict(FULL, n_layers=3)                                                       # layer 1 is the layer before the last
     model = DiscreteDenoisingDiffusion(make_cfg(dims), make_info(), device=D).eval()
     # (5, 75): 3 x 3 tiles, the last ones partial; (3, 140): 5 tiles a row, some of them without one key whose edges are free (the last
-    # layer with last_rows computes their attention part only: da_edge_layer_ex key_free)
+    # layer with a plan computes their attention part only: da_edge_layer_ex row_tiles)
     true = S.make_reaction_batch(B, n, seed=4, P=None)
     data = PlaceHolder(**{k: v.to(D) for k, v in true.items()})
     pos = S.shared_pos_encodings(true, 256, seed=3).to(D)
