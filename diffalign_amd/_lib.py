@@ -68,7 +68,7 @@ SIGNATURES = {
     'da_y_film': 'i:ppppppiiiip',
     'da_qkv_frag': 'i:ppppppiiip',
     'da_kv_pack': 'i:ppipiiip',
-    'da_edge_layer': 'i:pppippppppppfiiiiipqp', 'da_edge_layer_table': 'i:pppippppppppfiiiiipqppip', 'da_edge_in_classes': 'i:pipppppiiiip',
+    'da_edge_layer': 'i:pppippppppppfiiiiipqp', 'da_edge_layer_table': 'i:pppippppppppfiiiiipqppip', 'da_edge_in_classes': 'i:pipppppiiiip', 'da_edge_in_classes_keep': 'i:pipppppiiiiip',
     'da_edge_layer_stats': 'i:pppippppppppfiiiiipqpipp',
     'da_edge_layer_ex': 'i:pppippppppppfiiiiipqpip' + 'ppi' + 'pippp', 'da_edge_split_scratch_bytes_rows': 'q:qii',
     'da_edge_layer_tuning': 'i:iiiiii',

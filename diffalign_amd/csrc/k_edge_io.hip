@@ -707,6 +707,12 @@ __global__ void __launch_bounds__(OT_THR, 4) k_edge_out_tiles(const bf16_t* __re
   }
 }
 
+// the part of k_edge_in_table every call needs when the table itself is already in the scratch (same weights as the call that wrote it)
+__global__ void __launch_bounds__(256) k_edge_in_init(uint8_t* __restrict__ flags, int n_flags, int* __restrict__ hist, int n_hist) {
+  for (int t = threadIdx.x; t < n_flags; t += 256) flags[t] = 1;
+  for (int t = threadIdx.x; t < n_hist; t += 256) hist[t] = 0;
+}
+
 // ===================================================================================================
 #ifndef EXP_IOGRID_CAP
 #define EXP_IOGRID_CAP 2048
@@ -719,15 +725,16 @@ static inline int io_grid(int rows) { int g = (rows + 3) / 4; return g < 1 ? 1 :
 
 template <int DE, int HE>
 static int launch_in(const float* E_in, int de_in, const uint8_t* nm, const void* blob, void* E_out, int B, int n, hipStream_t s,
-                     uint8_t* sym_flags = nullptr, uint8_t* cls_map = nullptr) {
+                     uint8_t* sym_flags = nullptr, uint8_t* cls_map = nullptr, bool table_valid = false) {
   using C = EdgeIoCfg<DE, HE>;
   if (sym_flags) {                                    // scratch: [B] symmetric, [B] one-hot, 16-byte aligned table
     const int nt = (n + 31) / 32;
     uint4* T = reinterpret_cast<uint4*>(sym_flags + in_table_offset(B));
     int* hist = reinterpret_cast<int*>(sym_flags + in_hist_offset(B, de_in, DE));
     if (de_in <= 8) {
-      k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T, sym_flags, 2 * B, hist,
-                                                                                      B * IN_HIST);
+      if (table_valid) k_edge_in_init<<<1, 256, 0, s>>>(sym_flags, 2 * B, hist, B * IN_HIST);
+      else k_edge_in_table<DE, HE><<<1, 64, C::IN_BYTES + 32 * de_in * sizeof(float), s>>>(de_in, (const uint4*)blob, T, sym_flags, 2 * B, hist,
+                                                                                           B * IN_HIST);
       const dim3 grid(nt * (nt + 1) / 2, B);
       const size_t lds = 18 * (DE / 8) * 16 + 32 * 32 * de_in * sizeof(float);
       if (cls_map) k_edge_in_tiles<DE, true><<<grid, 256, lds, s>>>(E_in, de_in, nm, T, (uint4*)E_out, n, sym_flags, hist, cls_map);
@@ -777,18 +784,29 @@ int da_edge_in(const float* E_in, int de_in, const uint8_t* node_mask, const voi
 // pair in cls_map (B,n,n) -- the row of the table in `scratch` that holds the pair's hidden features -- and their part of E_h is
 // NOT written; the other graphs (flags cleared in `scratch`) get their hidden rows in E_h as da_edge_in writes them.
 // de_in <= 8 (the table path); scratch: da_edge_in_scratch_bytes(B, de_in, de) bytes.
-int da_edge_in_classes(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
-                       uint8_t* scratch, int B, int n, int de, int he, void* stream) {
+static int edge_in_classes_impl(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                                uint8_t* scratch, int B, int n, int de, int he, bool table_valid, void* stream) {
   DA_CHECK_ARG(de_in >= 1 && de_in <= 8, "da_edge_in_classes: input edge feature width %d not in 1..8", de_in);
   DA_CHECK_ARG(scratch != nullptr && cls_map != nullptr, "da_edge_in_classes: scratch / cls_map is null");
   if (B == 0 || n == 0) return DA_OK;
   int rc;
-  if (de == 64 && he == 128) rc = launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map);
-  else if (de == 32 && he == 32) rc = launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map);
+  if (de == 64 && he == 128) rc = launch_in<64, 128>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map, table_valid);
+  else if (de == 32 && he == 32) rc = launch_in<32, 32>(E_in, de_in, node_mask, blob, E_h, B, n, (hipStream_t)stream, scratch, cls_map, table_valid);
   else { da_set_error("da_edge_in_classes: dims (de=%d, hidden=%d) not built; built: (64,128), (32,32)", de, he); return DA_ERR_UNSUPPORTED; }
   if (rc) return rc;
   DA_CHECK_LAUNCH("da_edge_in_classes");
   return DA_OK;
+}
+int da_edge_in_classes(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                       uint8_t* scratch, int B, int n, int de, int he, void* stream) {
+  return edge_in_classes_impl(E_in, de_in, node_mask, blob, E_h, cls_map, scratch, B, n, de, he, false, stream);
+}
+// da_edge_in_classes for a caller that keeps `scratch` between calls: table_valid != 0 says that the scratch still holds the table an
+// earlier call with the SAME blob, B and de_in left there (it depends on the weights alone), so only the flags and class counts are
+// set up again (a 1-wave MLP evaluation of 15 us in front of every step's input stage otherwise).
+int da_edge_in_classes_keep(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                            uint8_t* scratch, int B, int n, int de, int he, int table_valid, void* stream) {
+  return edge_in_classes_impl(E_in, de_in, node_mask, blob, E_h, cls_map, scratch, B, n, de, he, table_valid != 0, stream);
 }
 
 // Scratch da_edge_in_sym needs: 2B flag bytes (symmetric, one-hot), the (de_in + 2) x de bf16 table of the one-hot path and

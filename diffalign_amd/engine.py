@@ -541,14 +541,22 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
             layer_film(pm, pm.layers[0], yh, B, film0)
             y_done0 = side.record_event()
     Eh = torch.empty(B, n, n, pm.de, dtype=torch.bfloat16, device=dev)
-    sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
+    # the input stage's scratch (flags, table, class counts) is kept per batch size: its table depends on the weights alone and is
+    # evaluated by the first call only (da_edge_in_classes_keep).  Calls on one stream are ordered; a re-packed model is a new object.
+    in_keep = pm.__dict__.setdefault('_in_scratch', {})
+    sym_flags = in_keep.get((B, dev))
+    table_valid = sym_flags is not None and os.environ.get('DA_KEEP_IN_TABLE', '1') != '0'      # (read per call: an A/B switch)
+    if sym_flags is None:
+        sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     # one-hot symmetric inputs (every diffusion state): the first layer takes its input rows from the input stage's table through a
     # one-byte class per pair, and the hidden tensor is neither written here nor read there
     table0 = None
     if TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None:
         cls_map = torch.empty(B, n, n, dtype=torch.uint8, device=dev)
-        L.check(lib.da_edge_in_classes(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags), _i(B),
-                                       _i(n), _i(pm.de), _i(pm.he), S), 'da_edge_in_classes')
+        L.check(lib.da_edge_in_classes_keep(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags), _i(B),
+                                            _i(n), _i(pm.de), _i(pm.he), _i(1 if table_valid else 0), S), 'da_edge_in_classes_keep')
+        if not torch.cuda.is_current_stream_capturing():     # (a captured call has not run yet: its table does not exist)
+            in_keep[(B, dev)] = sym_flags
         table0 = (cls_map, sym_flags)
     else:
         L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),

@@ -338,6 +338,11 @@ int da_edge_layer_stats(const void* E_in, void* E_out, const float* Q, int ldq, 
  * table-path graphs come from that table (in_scratch = the same scratch) instead of E_h.  de_in <= 8. */
 int da_edge_in_classes(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
                        uint8_t* scratch, int B, int n, int de, int he, void* stream);
+/* da_edge_in_classes for a caller that keeps `scratch` between calls (no counterpart in the reference: its mlp_in_E runs on every pair,
+ * transformer_model_with_y.py:657-661): table_valid != 0 = the scratch still holds the table an earlier call with the same blob, B and
+ * de_in left there; only the flags and class counts are then set up again. */
+int da_edge_in_classes_keep(const float* E_in, int de_in, const uint8_t* node_mask, const void* blob, void* E_h, uint8_t* cls_map,
+                            uint8_t* scratch, int B, int n, int de, int he, int table_valid, void* stream);
 int da_edge_layer_table(const void* E_in, void* E_out, const float* Q, int ldq, const void* KV_frag, const uint8_t* node_mask,
                         const float* ye2p1, const float* ebias, const float* yx1, const float* yx2p1, float* newX_in,
                         const void* blob, float qscale, int B, int n, int de, int dx, int dff, void* split_scratch,
