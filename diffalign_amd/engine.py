@@ -167,11 +167,11 @@ def layer_film(pm: PackedModel, lw: dict, y, B, out):
     return out
 
 
-def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de):
+def edge_stats_after_in(scratch, E_bf16, B, n, de_in, de, out=None):
     """Statistics partials of the input stage's output: from the class counts da_edge_in_sym left in `scratch` for the graphs
     its table served (no pass over the hidden tensor), da_edge_stats for the others."""
     nch = stat_chunks(n)
-    st = torch.empty(B, nch, 4, de, dtype=torch.float32, device=E_bf16.device)
+    st = out if out is not None else torch.empty(B, nch, 4, de, dtype=torch.float32, device=E_bf16.device)
     lib = L.lib()
     if de_in <= 8:
         L.check(lib.da_edge_stats_table(L.ptr(scratch), L.ptr(st), _i(B), _i(de_in), _i(de), _i(nch), L.stream()),
@@ -508,19 +508,29 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
                     'da_align_index')
 
     xin_done = align_done = None
+    # Which of the two input chains runs on the caller's stream: a cross-stream event costs ~14 us before the other stream starts, and
+    # the node input kernel (150 workgroups) must get its CUs BEFORE the class pass of the edge stage floods the dispatcher with 2,880
+    # small ones (side by side from the start it takes 93 instead of 32 us, and the node chain is the longer one).  So the node chain
+    # starts at once on the caller's stream and the edge input stage follows on the node side stream (DA_EDGE_IN_ON_SIDE=0: the
+    # other way round, as before the stage's table was kept between calls).
+    # (Not under HIP-graph capture: replaying a step captured this way faulted inside the runtime, like every other change of what the
+    # side streams do at the start of a captured step; captured steps keep the arrangement they had.)
+    edge_in_on_side = (side is not None and side2 is not None and not torch.cuda.is_current_stream_capturing()
+                       and os.environ.get('DA_EDGE_IN_ON_SIDE', '1') != '0')
     if side2 is None:
         node_features()
         alignment()
     else:
         in_ready = main.record_event()
-        with torch.cuda.stream(side2):
-            side2.wait_event(in_ready)
-            if pending is not None:
-                side2.wait_event(pending[0])
-            node_features()
-            xin_done = side2.record_event()
-            alignment()
-            align_done = side2.record_event()
+        if not edge_in_on_side:
+            with torch.cuda.stream(side2):
+                side2.wait_event(in_ready)
+                if pending is not None:
+                    side2.wait_event(pending[0])
+                node_features()
+                xin_done = side2.record_event()
+                alignment()
+                align_done = side2.record_event()
     yh = torch.empty(B, pm.dy, device=dev)
     film0 = film_buffers(pm, B, dev) if side is not None else None
     y_done0 = None
@@ -550,24 +560,43 @@ def model_forward(pm: PackedModel, X, E, y, node_mask, atom_map_numbers=None, po
         sym_flags = torch.empty(int(lib.da_edge_in_scratch_bytes(_i(B), _i(pm.de_in), _i(pm.de))), dtype=torch.uint8, device=dev)
     # one-hot symmetric inputs (every diffusion state): the first layer takes its input rows from the input stage's table through a
     # one-byte class per pair, and the hidden tensor is neither written here nor read there
-    table0 = None
-    if TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None:
-        cls_map = torch.empty(B, n, n, dtype=torch.uint8, device=dev)
-        L.check(lib.da_edge_in_classes_keep(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags), _i(B),
-                                            _i(n), _i(pm.de), _i(pm.he), _i(1 if table_valid else 0), S), 'da_edge_in_classes_keep')
-        if not torch.cuda.is_current_stream_capturing():     # (a captured call has not run yet: its table does not exist)
-            in_keep[(B, dev)] = sym_flags
-        table0 = (cls_map, sym_flags)
+    use_table = TABLE_IN and pm.de_in <= 8 and side is not None and side2 is not None
+    cls_map = torch.empty(B, n, n, dtype=torch.uint8, device=dev) if use_table else None
+    st0 = torch.empty(B, stat_chunks(n), 4, pm.de, dtype=torch.float32, device=dev)
+
+    def edge_input_stage():                          # (buffers allocated above, on the caller's stream, whichever stream runs this)
+        if use_table:
+            L.check(lib.da_edge_in_classes_keep(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cls_map), L.ptr(sym_flags),
+                                                _i(B), _i(n), _i(pm.de), _i(pm.he), _i(1 if table_valid else 0), L.stream()),
+                    'da_edge_in_classes_keep')
+            if not torch.cuda.is_current_stream_capturing():     # (a captured call has not run yet: its table does not exist)
+                in_keep[(B, dev)] = sym_flags
+        else:
+            L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
+                                       _i(pm.he), L.stream()), 'da_edge_in_sym')
+        edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de, out=st0)
+
+    table0 = (cls_map, sym_flags) if use_table else None
+    if edge_in_on_side:
+        with torch.cuda.stream(side2):
+            side2.wait_event(in_ready)
+            edge_input_stage()
+            ein_done = side2.record_event()
+            alignment()                              # (read by the output stage only)
+            align_done = side2.record_event()
+        if pending is not None:
+            main.wait_event(pending[0])              # (its tensors were allocated on this stream: held until here)
+            pending = None
+        node_features()
+        main.wait_event(ein_done)
     else:
-        L.check(lib.da_edge_in_sym(L.ptr(E), _i(pm.de_in), L.ptr(nm), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(sym_flags), _i(B), _i(n), _i(pm.de),
-                                   _i(pm.he), S), 'da_edge_in_sym')
+        edge_input_stage()
+        if pending is not None:
+            main.wait_event(pending[0])              # (its tensors were allocated on this stream: held until here)
+            pending = None
+        if xin_done is not None:
+            main.wait_event(xin_done)
     # ---- layers
-    st0 = edge_stats_after_in(sym_flags, Eh, B, n, pm.de_in, pm.de)
-    if pending is not None:
-        main.wait_event(pending[0])                  # (its tensors were allocated on this stream: held until here)
-        pending = None
-    if xin_done is not None:
-        main.wait_event(xin_done)
     if side is None:
         for li, lw in enumerate(pm.layers):
             Xh, Eh, yh = layer_forward(pm, lw, Xh, Eh, yh, nm, st0 if li == 0 else None, B, n)
