@@ -79,6 +79,46 @@ def test_edge_in_table_path_shapes(n):
     assert scratch[:2 * B].cpu().tolist() == [1] * (2 * B)
 
 
+def test_edge_in_classes_keeps_its_table_between_calls():
+    """da_edge_in_classes_keep: a second call on the kept scratch with table_valid = 1 (other input graphs, one of them not one-hot)
+    leaves the same class map, flags, class counts and table -- the whole scratch -- and the same hidden rows of the graph that fell
+    back, as a fresh da_edge_in_classes call on those graphs."""
+    from diffalign_amd import engine, _lib as L
+    hd = FULL['hidden_dims']
+    m, sd = build(FULL, 1, seed=7)
+    pm = m._pack(torch.device(D))
+    B, n = 4, 45
+    i_ = engine._i
+
+    def graphs(seed, spoil):
+        g = torch.Generator().manual_seed(seed)
+        cl = torch.randint(0, KE, (B, n, n), generator=g)
+        cl = torch.triu(cl, 1); cl = cl + cl.transpose(1, 2)
+        E = F.one_hot(cl, KE).float()
+        if spoil:
+            E[1, 3, 4, 2] = 0.5                                   # graph 1 is not one-hot: it leaves the table path
+        return E.to(D), L.as_u8((torch.rand(B, n, generator=g) < 0.8).to(D))
+
+    nbytes = int(L.lib().da_edge_in_scratch_bytes(i_(B), i_(KE), i_(hd['de'])))
+    args = (i_(B), i_(n), i_(hd['de']), i_(FULL['hidden_mlp_dims']['E']))
+    kept = torch.zeros(nbytes, dtype=torch.uint8, device=D)
+    E1, nm1 = graphs(1, False)
+    Eh = torch.zeros(B, n, n, hd['de'], dtype=torch.bfloat16, device=D); cm = torch.zeros(B, n, n, dtype=torch.uint8, device=D)
+    L.check(L.lib().da_edge_in_classes_keep(L.ptr(E1), i_(KE), L.ptr(nm1), L.ptr(pm.in_E), L.ptr(Eh), L.ptr(cm), L.ptr(kept), *args, i_(0), L.stream()), 'keep 0')
+    for seed, spoil in ((2, False), (3, True)):
+        E2, nm2 = graphs(seed, spoil)
+        Eh_k = torch.zeros_like(Eh); cm_k = torch.zeros_like(cm)
+        L.check(L.lib().da_edge_in_classes_keep(L.ptr(E2), i_(KE), L.ptr(nm2), L.ptr(pm.in_E), L.ptr(Eh_k), L.ptr(cm_k), L.ptr(kept), *args, i_(1), L.stream()), 'keep 1')
+        fresh = torch.zeros(nbytes, dtype=torch.uint8, device=D)
+        Eh_f = torch.zeros_like(Eh); cm_f = torch.zeros_like(cm)
+        L.check(L.lib().da_edge_in_classes(L.ptr(E2), i_(KE), L.ptr(nm2), L.ptr(pm.in_E), L.ptr(Eh_f), L.ptr(cm_f), L.ptr(fresh), *args, L.stream()), 'fresh')
+        flags = fresh[:2 * B].cpu().tolist()
+        assert flags == ([1] * (2 * B) if not spoil else [1, 1, 1, 1, 1, 0, 1, 1]) or (spoil and flags[B + 1] == 0)
+        assert torch.equal(kept, fresh)                                      # flags, table, class counts
+        ok = torch.tensor([bool(flags[b] and flags[B + b]) for b in range(B)], device=D)
+        assert torch.equal(cm_k[ok], cm_f[ok]) and torch.equal(Eh_k[~ok], Eh_f[~ok])
+
+
 @pytest.mark.parametrize('dims', [FULL, TINY], ids=['full', 'tiny'])
 def test_stages_vs_oracle(dims):
     """input stage, one layer, output stage -- each against the oracle on the same (bf16-rounded) inputs."""
